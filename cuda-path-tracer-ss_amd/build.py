@@ -1,0 +1,108 @@
+"""Builds every native artefact of the repo, in-tree.
+
+  libptss.so        hipcc --offload-arch=gfx950   csrc/*.hip        the product (kernels + C-ABI)
+  libptss_host.so   g++                            host/*.cpp        host mirror (Scene, camera, TGA, probes)
+  ptss_main         hipcc (host only) + libptss    host/main.cpp     headless drop-in of the reference's main()
+  oracle/_build/liboracle.so   g++ -fopenmp        oracle/*.cpp      CPU restatement (test infrastructure only)
+
+Both sides of the parity contract are compiled with -ffp-contract=off and without fast-math
+(DESIGN.md "Parity"); the CPU objects use -mfma -mavx2 so that ptm::fma is one correctly rounded
+instruction (any x86-64 server since 2013; the GPU box's host qualifies).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INC = os.path.join(ROOT, "include")
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+ORACLE = os.path.join(ROOT, "oracle")
+LIBDIR = os.path.join(HERE, "lib")
+
+FP_FLAGS = ["-ffp-contract=off", "-fno-fast-math"]
+CPU_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-mfma", "-mavx2", "-Wall", "-Wno-unused-function"] + FP_FLAGS
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt",
+             "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"] + FP_FLAGS
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _headers():
+    hs = []
+    for d in (INC, CSRC, HOST, ORACLE):
+        if os.path.isdir(d):
+            hs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
+    return hs
+
+
+def build_host(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libptss_host.so")
+    srcs = [os.path.join(HOST, f) for f in ("Scene.cpp", "HostOps.cpp", "host_capi.cpp")]
+    if force or _newer(out, srcs + _headers()):
+        _run(["g++"] + CPU_FLAGS + ["-shared", "-I", INC, "-I", CSRC, "-I", HOST] + srcs + ["-o", out])
+    return out
+
+
+def build_oracle(force=False):
+    outdir = os.path.join(ORACLE, "_build")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "liboracle.so")
+    srcs = [os.path.join(ORACLE, "oracle.cpp")]
+    if force or _newer(out, srcs + _headers()):
+        _run(["g++"] + CPU_FLAGS + ["-fopenmp", "-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
+    return out
+
+
+def build_device(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libptss.so")
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if force or _newer(out, srcs + _headers()):
+        _run([hipcc] + HIP_FLAGS + ["-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
+    return out
+
+
+def build_main(force=False):
+    out = os.path.join(LIBDIR, "ptss_main")
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "CudaTracer.cpp", "Scene.cpp", "HostOps.cpp")]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if force or _newer(out, srcs + _headers() + [os.path.join(LIBDIR, "libptss.so")]):
+        _run([hipcc, "-O2", "-std=c++17", "-x", "c++"] + FP_FLAGS + ["-I", INC, "-I", CSRC, "-I", HOST] + srcs +
+             ["-D__HIP_PLATFORM_AMD__", "-L", LIBDIR, "-lptss", "-L/opt/rocm/lib", "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
+def build_all(force=False):
+    outs = [build_host(force), build_oracle(force), build_device(force)]
+    m = build_main(force)
+    if m:
+        outs.append(m)
+    return outs
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    what = [a for a in sys.argv[1:] if not a.startswith("-")]
+    table = {"host": build_host, "oracle": build_oracle, "device": build_device, "main": build_main}
+    if not what:
+        build_all(force)
+    for w in what:
+        table[w](force)

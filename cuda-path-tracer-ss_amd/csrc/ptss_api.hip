@@ -1,0 +1,596 @@
+// ptss_api.hip — context management and the frame driver behind include/ptss.h.
+//
+// ptss_generate_frame is the reference's generateFrame (CudaTracer/CudaTracer.cu:587-647) with the
+// host taken out of the inner loop: the per-bounce live-ray count stays on the device
+// (FrameBuffers::counts), every bounce kernel is launched unconditionally and applies the
+// reference's `numRays > 128` guard itself, so a frame is one uninterrupted stream of launches
+// with at most one event wait at the end (cfg.syncEachFrame, the reference's :639-642).
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ptss.h"
+#include "ptss_device.h"
+
+using namespace ptv;
+
+namespace {
+
+thread_local std::string g_detail;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    g_detail = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return fail(PTSS_EHIP, #expr, _e); \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ptss_context {
+    ptss_render_config cfg{};
+    hipStream_t stream = nullptr;
+    ptss::TileMap tile{};
+    ptss::SceneLayout layout{};
+    float4* dScene = nullptr;
+    float* dPool[2] = {nullptr, nullptr};
+    uint32_t* dRngHome = nullptr;
+    uint32_t* dCounts = nullptr;
+    unsigned long long* dTotal = nullptr;
+    uint32_t* dAccumOwned = nullptr;
+    uint32_t* dAccum = nullptr;  // owned or bound
+    float* dFsum = nullptr;
+    uint32_t capacity = 0, numPixels = 0;
+    float defaultColor[3] = {0, 0, 0};
+    // ProgramData (CudaTracer.h:32-42)
+    ptss_camera camera{};
+    int lastResetTick = 0;
+    int lastTicks = 0;
+    unsigned maxIterations = 15;
+    bool resetTicksThisFrame = true;
+    bool usePathTracer = true;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    float lastMs = 0.0f;
+    int gridBlocks = 0;
+    // bounce-kernel timing (cfg.timeKernels)
+    std::vector<EventPair> evFree, evBusy;
+    double kernelMs = 0.0;
+    unsigned long long kernelLaunches = 0;
+};
+
+namespace {
+
+void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float4>& blob) {
+    auto u2f = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    L.numSpheres = (int)s.numSpheres;
+    L.numTriangles = (int)s.numTriangles;
+    L.numMaterials = (int)s.numMaterials;
+    L.numPointLights = (int)s.numPointLights;
+    L.numAreaLights = (int)s.numAreaLights;
+    int off = 0;
+    L.offSphere = off;      off += L.numSpheres;
+    L.offSphereMat = off;   off += (L.numSpheres + 3) / 4;
+    L.offTri = off;         off += 3 * L.numTriangles;
+    L.offTriNormal = off;   off += 3 * L.numTriangles;
+    L.offTriVert = off;     off += 2 * L.numTriangles;
+    L.offMaterial = off;    off += 5 * L.numMaterials;
+    L.offPointLight = off;  off += 2 * L.numPointLights;
+    L.offAreaLight = off;   off += L.numAreaLights;
+    L.totalVec4 = off;
+    blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
+    for (int i = 0; i < L.numSpheres; ++i) {
+        const ptss_sphere& sp = s.spheres[i];
+        // radius*radius is the same single rounding the reference performs per test (Primitives.h:113)
+        blob[L.offSphere + i] = float4{sp.position.x, sp.position.y, sp.position.z, sp.radius * sp.radius};
+        reinterpret_cast<int*>(&blob[L.offSphereMat])[i] = sp.materialIdx;
+    }
+    for (int i = 0; i < L.numTriangles; ++i) {
+        const ptss_triangle& t = s.triangles[i];
+        const vec3 e1 = t.vertex1 - t.vertex0;  // Primitives.h:34-35, hoisted (same subtraction, same bits)
+        const vec3 e2 = t.vertex2 - t.vertex0;
+        blob[L.offTri + 3 * i + 0] = float4{t.vertex0.x, t.vertex0.y, t.vertex0.z, u2f((uint32_t)t.materialIdx)};
+        blob[L.offTri + 3 * i + 1] = float4{e1.x, e1.y, e1.z, 0};
+        blob[L.offTri + 3 * i + 2] = float4{e2.x, e2.y, e2.z, 0};
+        blob[L.offTriNormal + 3 * i + 0] = float4{t.normal0.x, t.normal0.y, t.normal0.z, 0};
+        blob[L.offTriNormal + 3 * i + 1] = float4{t.normal1.x, t.normal1.y, t.normal1.z, 0};
+        blob[L.offTriNormal + 3 * i + 2] = float4{t.normal2.x, t.normal2.y, t.normal2.z, 0};
+        blob[L.offTriVert + 2 * i + 0] = float4{t.vertex1.x, t.vertex1.y, t.vertex1.z, 0};
+        blob[L.offTriVert + 2 * i + 1] = float4{t.vertex2.x, t.vertex2.y, t.vertex2.z, 0};
+    }
+    for (int i = 0; i < L.numMaterials; ++i) {
+        const ptss_material& m = s.materials[i];
+        float4* o = &blob[L.offMaterial + 5 * i];
+        o[0] = float4{m.diffuseColor.x, m.diffuseColor.y, m.diffuseColor.z, m.diffAvg};
+        o[1] = float4{m.specularColor.x, m.specularColor.y, m.specularColor.z, m.specAvg};
+        o[2] = float4{m.absorption.x, m.absorption.y, m.absorption.z, m.refrAvg};
+        o[3] = float4{m.emmitance.x, m.emmitance.y, m.emmitance.z, m.roughness};
+        o[4] = float4{m.specularExponent, m.indexOfRefraction, u2f((uint32_t)(unsigned char)m.flags), 0};
+    }
+    for (int i = 0; i < L.numPointLights; ++i) {
+        const ptss_point_light& p = s.pointLights[i];
+        blob[L.offPointLight + 2 * i + 0] = float4{p.position.x, p.position.y, p.position.z, 0};
+        blob[L.offPointLight + 2 * i + 1] = float4{p.power.x, p.power.y, p.power.z, 0};
+    }
+    for (int i = 0; i < L.numAreaLights; ++i) {
+        const ptss_area_light& a = s.areaLights[i];
+        blob[L.offAreaLight + i] = float4{a.power.x, a.power.y, a.power.z, u2f((uint32_t)a.triangleIdx)};
+    }
+}
+
+int validateScene(const ptss_scene_desc& s) {
+    if ((s.numSpheres && !s.spheres) || (s.numTriangles && !s.triangles) || (s.numMaterials && !s.materials) ||
+        (s.numPointLights && !s.pointLights) || (s.numAreaLights && !s.areaLights))
+        return fail(PTSS_EINVAL, "scene: null array with non-zero count");
+    for (size_t i = 0; i < s.numSpheres; ++i)
+        if (s.spheres[i].materialIdx < 0 || (size_t)s.spheres[i].materialIdx >= s.numMaterials)
+            return fail(PTSS_EINVAL, "scene: sphere materialIdx out of range");
+    for (size_t i = 0; i < s.numTriangles; ++i)
+        if (s.triangles[i].materialIdx < 0 || (size_t)s.triangles[i].materialIdx >= s.numMaterials)
+            return fail(PTSS_EINVAL, "scene: triangle materialIdx out of range");
+    for (size_t i = 0; i < s.numAreaLights; ++i)
+        if (s.areaLights[i].triangleIdx < 0 || (size_t)s.areaLights[i].triangleIdx + 1 >= s.numTriangles)
+            return fail(PTSS_EINVAL, "scene: area light needs triangles [triangleIdx, triangleIdx+1]");
+    return PTSS_OK;
+}
+
+ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int sample) {
+    ptss::FrameBuffers fb{};
+    fb.pool[0] = c->dPool[0];
+    fb.pool[1] = c->dPool[1];
+    fb.rngHome = c->dRngHome;
+    fb.counts = c->dCounts;
+    fb.totalRayBounces = c->dTotal;
+    fb.accum = c->dAccum;
+    fb.fsum = c->dFsum;
+    fb.pixels = pixels;
+    fb.capacity = c->capacity;
+    fb.numPixels = c->numPixels;
+    fb.inverseTicks = 1.f / (sample + 1);  // CudaTracer.cu:94
+    fb.defaultColor[0] = c->defaultColor[0];
+    fb.defaultColor[1] = c->defaultColor[1];
+    fb.defaultColor[2] = c->defaultColor[2];
+    return fb;
+}
+
+void drainKernelEvents(ptss_context* c, bool wait) {
+    size_t k = 0;
+    for (size_t i = 0; i < c->evBusy.size(); ++i) {
+        EventPair p = c->evBusy[i];
+        hipError_t q = wait ? hipEventSynchronize(p.b) : hipEventQuery(p.b);
+        if (q == hipSuccess) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                c->kernelMs += ms;
+                c->kernelLaunches += 1;
+            }
+            c->evFree.push_back(p);
+        } else {
+            c->evBusy[k++] = p;
+        }
+    }
+    c->evBusy.resize(k);
+    (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptss_version(void) { return 100; }
+
+const char* ptss_error_string(int code) {
+    switch (code) {
+        case PTSS_OK: return "ok";
+        case PTSS_EINVAL: return "invalid argument";
+        case PTSS_EHIP: return "HIP runtime error";
+        case PTSS_ENODEVICE: return "no usable HIP device";
+        case PTSS_ENOMEM: return "out of memory";
+        case PTSS_ERANGE: return "buffer too small or index out of range";
+        default: return "unknown error";
+    }
+}
+
+const char* ptss_last_error_detail(void) { return g_detail.c_str(); }
+
+int ptss_default_config(ptss_render_config* cfg) {
+    if (!cfg) return fail(PTSS_EINVAL, "cfg is null");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->width = 512;  // DIM, CudaUtils.h:7
+    cfg->height = 512;
+    cfg->seed = 0x5EEDull;
+    cfg->maxIterations = 15;  // CudaTracer.h:39
+    cfg->device = 0;
+    cfg->tileRank = 0;
+    cfg->tileWorld = 1;
+    cfg->bandRows = 8;
+    cfg->syncEachFrame = 1;
+    cfg->floatAccumulator = 0;
+    cfg->timeKernels = 0;
+    return PTSS_OK;
+}
+
+int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, ptss_context** out) {
+    if (!scene || !cfg || !out) return fail(PTSS_EINVAL, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0 || (long long)cfg->width * cfg->height > (1ll << 31) - 256)
+        return fail(PTSS_EINVAL, "bad frame size");
+    if (cfg->maxIterations == 0 || cfg->maxIterations > (unsigned)ptss::kMaxBounces)
+        return fail(PTSS_EINVAL, "maxIterations must be in [1, 64]");
+    if (cfg->tileWorld <= 0 || cfg->tileRank < 0 || cfg->tileRank >= cfg->tileWorld || cfg->bandRows <= 0)
+        return fail(PTSS_EINVAL, "bad tile spec");
+    int rc = validateScene(*scene);
+    if (rc != PTSS_OK) return rc;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(PTSS_ENODEVICE, "hipGetDeviceCount found no device (libptss has no CPU path)", e);
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(PTSS_ENODEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    ptss_context* c = new (std::nothrow) ptss_context();
+    if (!c) return fail(PTSS_ENOMEM, "context");
+    c->cfg = *cfg;
+    c->maxIterations = cfg->maxIterations;
+    c->defaultColor[0] = scene->defaultColor.x;
+    c->defaultColor[1] = scene->defaultColor.y;
+    c->defaultColor[2] = scene->defaultColor.z;
+    // Camera(), RenderStructs.h:51-52
+    c->camera.rotation = q4(1, 0, 0, 0);
+    c->camera.position = v3(0, 0, 0);
+    c->camera.zNear = -0.1f;
+    c->camera.zFar = -100.0f;
+    c->camera.fieldOfView = ptm::kPi / 2.0f;
+
+    int localRows = 0;
+    for (int y = 0; y < cfg->height; ++y)
+        if ((y / cfg->bandRows) % cfg->tileWorld == cfg->tileRank) ++localRows;
+    c->tile = ptss::TileMap{cfg->width, cfg->height, localRows, cfg->tileRank, cfg->tileWorld, cfg->bandRows};
+    c->numPixels = (uint32_t)cfg->width * (uint32_t)localRows;
+    c->capacity = ((c->numPixels + 255u) / 256u) * 256u;
+    if (c->capacity == 0) c->capacity = 256;
+
+    std::vector<float4> blob;
+    packScene(*scene, c->layout, blob);
+    const size_t ldsBytes = (size_t)c->layout.totalVec4 * sizeof(float4);
+    if (ldsBytes > 150 * 1024) {
+        delete c;
+        return fail(PTSS_EINVAL, "scene does not fit the 160 KiB LDS staging budget");
+    }
+
+#define CREATE_TRY(expr)                                  \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) {                           \
+            int _rc = fail(_e == hipErrorOutOfMemory ? PTSS_ENOMEM : PTSS_EHIP, #expr, _e); \
+            ptss_destroy(c);                              \
+            return _rc;                                   \
+        }                                                 \
+    } while (0)
+
+    CREATE_TRY(hipMalloc(&c->dScene, blob.size() * sizeof(float4)));
+    CREATE_TRY(hipMemcpy(c->dScene, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+    const size_t poolBytes = (size_t)ptss::kRayPlanes * c->capacity * sizeof(float);
+    CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
+    CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
+    CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kRngPlanes * c->capacity * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dCounts, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->dCounts, 0, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dTotal, sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(c->dTotal, 0, sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->dAccumOwned, (size_t)3 * c->capacity * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->dAccumOwned, 0, (size_t)3 * c->capacity * sizeof(uint32_t)));
+    c->dAccum = c->dAccumOwned;
+    if (cfg->floatAccumulator) {
+        CREATE_TRY(hipMalloc(&c->dFsum, (size_t)3 * c->capacity * sizeof(float)));
+        CREATE_TRY(hipMemset(c->dFsum, 0, (size_t)3 * c->capacity * sizeof(float)));
+    }
+    CREATE_TRY(hipEventCreate(&c->evStart));
+    CREATE_TRY(hipEventCreate(&c->evStop));
+
+    // curandSetupKernel (CudaTracer.cu:722-724): per-pixel subsequence via the 2^67 jump table
+    {
+        std::vector<uint32_t> table(ptrng::kJumpTableWords);
+        ptrng::build_subsequence_table(table.data());
+        uint32_t* dTable = nullptr;
+        CREATE_TRY(hipMalloc(&dTable, table.size() * sizeof(uint32_t)));
+        hipError_t e1 = hipMemcpy(dTable, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        hipError_t e2 = e1 == hipSuccess ? ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->tile, cfg->seed, dTable) : e1;
+        hipError_t e3 = e2 == hipSuccess ? hipDeviceSynchronize() : e2;
+        (void)hipFree(dTable);
+        CREATE_TRY(e3);
+    }
+
+    // persistent-style grid: enough workgroups to fill every CU at the kernel's occupancy, grid-stride beyond
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    int perCU = ptss::bounceOccupancyBlocksPerCU(ldsBytes);
+    if (perCU <= 0) perCU = 4;
+    c->gridBlocks = prop.multiProcessorCount * perCU;
+    const int needed = (int)((c->numPixels + ptss::kBlock - 1) / ptss::kBlock);
+    if (c->gridBlocks > needed) c->gridBlocks = needed > 0 ? needed : 1;
+#undef CREATE_TRY
+
+    *out = c;
+    return PTSS_OK;
+}
+
+int ptss_destroy(ptss_context* c) {
+    if (!c) return PTSS_OK;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    drainKernelEvents(c, true);
+    for (EventPair& p : c->evFree) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    (void)hipFree(c->dScene);
+    (void)hipFree(c->dPool[0]);
+    (void)hipFree(c->dPool[1]);
+    (void)hipFree(c->dRngHome);
+    (void)hipFree(c->dCounts);
+    (void)hipFree(c->dTotal);
+    (void)hipFree(c->dAccumOwned);
+    (void)hipFree(c->dFsum);
+    delete c;
+    return PTSS_OK;
+}
+
+int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    hipStream_t st = c->stream;
+    c->lastTicks = ticks;
+
+    if (c->resetTicksThisFrame) {  // CudaTracer.cu:602-608
+        c->lastResetTick = ticks;
+        HIP_TRY(ptss::launchClear(st, frameBuffers(c, pixels, 0)));
+        c->resetTicksThisFrame = false;
+    }
+    const int sample = ticks - c->lastResetTick;
+    const ptss::FrameBuffers fb = frameBuffers(c, pixels, sample);
+
+    if (c->cfg.syncEachFrame) HIP_TRY(hipEventRecord(c->evStart, st));  // :611
+
+    const int numIterations = c->usePathTracer ? (int)c->maxIterations : 1;  // :620
+
+    ptss::EyeParams eye;
+    eye.camera = c->camera;
+    eye.s = -2 * ptm::tan(c->camera.fieldOfView * 0.5f);  // :334
+    eye.aspect = (float)c->tile.height / (float)c->tile.width;
+    eye.invW = 1.0f / c->tile.width;
+    eye.invH = 1.0f / c->tile.height;
+    HIP_TRY(ptss::launchEyeRays(st, fb, c->tile, eye, numIterations));  // :614
+
+    if (c->cfg.timeKernels) drainKernelEvents(c, false);
+    for (int i = 0; i < numIterations; ++i) {  // :622-633, guard evaluated on the device
+        EventPair ev{nullptr, nullptr};
+        if (c->cfg.timeKernels) {
+            if (c->evFree.empty()) {
+                if (c->evBusy.size() >= 4096) drainKernelEvents(c, true);
+                if (c->evFree.empty()) {
+                    HIP_TRY(hipEventCreate(&ev.a));
+                    HIP_TRY(hipEventCreate(&ev.b));
+                }
+            }
+            if (!ev.a) {
+                ev = c->evFree.back();
+                c->evFree.pop_back();
+            }
+            HIP_TRY(hipEventRecord(ev.a, st));
+        }
+        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->gridBlocks));
+        if (c->cfg.timeKernels) {
+            HIP_TRY(hipEventRecord(ev.b, st));
+            c->evBusy.push_back(ev);
+        }
+    }
+    HIP_TRY(ptss::launchFlush(st, fb, numIterations));  // :637
+
+    if (c->cfg.syncEachFrame) {  // :639-642
+        HIP_TRY(hipEventRecord(c->evStop, st));
+        HIP_TRY(hipEventSynchronize(c->evStop));
+        HIP_TRY(hipEventElapsedTime(&c->lastMs, c->evStart, c->evStop));
+    }
+    return PTSS_OK;
+}
+
+int ptss_set_camera(ptss_context* c, const ptss_camera* camera) {
+    if (!c || !camera) return fail(PTSS_EINVAL, "null argument");
+    c->camera = *camera;
+    c->resetTicksThisFrame = true;
+    return PTSS_OK;
+}
+
+int ptss_get_camera(const ptss_context* c, ptss_camera* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->camera;
+    return PTSS_OK;
+}
+
+int ptss_request_reset(ptss_context* c) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    c->resetTicksThisFrame = true;
+    return PTSS_OK;
+}
+
+int ptss_set_mode(ptss_context* c, int usePathTracer) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    c->usePathTracer = usePathTracer != 0;
+    c->resetTicksThisFrame = true;
+    return PTSS_OK;
+}
+
+int ptss_set_max_iterations(ptss_context* c, unsigned int maxIterations) {
+    if (!c || maxIterations == 0 || maxIterations > (unsigned)ptss::kMaxBounces)
+        return fail(PTSS_EINVAL, "maxIterations must be in [1, 64]");
+    c->maxIterations = maxIterations;
+    return PTSS_OK;
+}
+
+int ptss_set_stream(ptss_context* c, void* hipStream) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    c->stream = (hipStream_t)hipStream;
+    return PTSS_OK;
+}
+
+int ptss_bind_accumulator(ptss_context* c, uint32_t* dev) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    c->dAccum = dev ? dev : c->dAccumOwned;
+    return PTSS_OK;
+}
+
+int ptss_accumulator_devptr(ptss_context* c, uint32_t** out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->dAccum;
+    return PTSS_OK;
+}
+
+int ptss_float_accumulator_devptr(ptss_context* c, float** out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->dFsum;
+    return PTSS_OK;
+}
+
+int ptss_alloc_pixels(ptss_context* c, ptss_uchar4** out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMalloc(out, (size_t)c->capacity * sizeof(ptss_uchar4)));
+    HIP_TRY(hipMemset(*out, 0, (size_t)c->capacity * sizeof(ptss_uchar4)));
+    return PTSS_OK;
+}
+
+int ptss_free_pixels(ptss_context* c, ptss_uchar4* dev) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    HIP_TRY(hipFree(dev));
+    return PTSS_OK;
+}
+
+int ptss_local_pixels(const ptss_context* c, size_t* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->numPixels;
+    return PTSS_OK;
+}
+
+int ptss_local_rows(const ptss_context* c, int* rows, int cap, int* count) {
+    if (!c || !count) return fail(PTSS_EINVAL, "null argument");
+    int n = 0;
+    for (int y = 0; y < c->tile.height; ++y) {
+        if ((y / c->tile.bandRows) % c->tile.world != c->tile.rank) continue;
+        if (rows) {
+            if (n >= cap) return fail(PTSS_ERANGE, "rows[] too small");
+            rows[n] = y;
+        }
+        ++n;
+    }
+    *count = n;
+    return PTSS_OK;
+}
+
+int ptss_synchronize(ptss_context* c) {
+    if (!c) return fail(PTSS_EINVAL, "ctx is null");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTSS_OK;
+}
+
+int ptss_read_accumulator(ptss_context* c, uint32_t* host, size_t count) {
+    if (!c || !host) return fail(PTSS_EINVAL, "null argument");
+    if (count != (size_t)3 * c->numPixels) return fail(PTSS_ERANGE, "count must be 3 * local pixels");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->dAccum, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_read_float_accumulator(ptss_context* c, float* host, size_t count) {
+    if (!c || !host) return fail(PTSS_EINVAL, "null argument");
+    if (!c->dFsum) return fail(PTSS_EINVAL, "context was created without floatAccumulator");
+    if (count != (size_t)3 * c->numPixels) return fail(PTSS_ERANGE, "count must be 3 * local pixels");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->dFsum, count * sizeof(float), hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_read_pixels(ptss_context* c, const ptss_uchar4* dev, ptss_uchar4* host, size_t count) {
+    if (!c || !dev || !host) return fail(PTSS_EINVAL, "null argument");
+    if (count > c->numPixels) return fail(PTSS_ERANGE, "count exceeds local pixels");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, dev, count * sizeof(ptss_uchar4), hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_read_rng_state(ptss_context* c, size_t local_pixel, uint32_t* out6) {
+    if (!c || !out6) return fail(PTSS_EINVAL, "null argument");
+    if (local_pixel >= c->numPixels) return fail(PTSS_ERANGE, "pixel out of range");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < ptss::kRngPlanes; ++k)
+        HIP_TRY(hipMemcpy(&out6[k], c->dRngHome + (size_t)k * c->capacity + local_pixel, sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_last_pass_ms(ptss_context* c, float* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->lastMs;
+    return PTSS_OK;
+}
+
+int ptss_samples_since_reset(const ptss_context* c, int* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = c->resetTicksThisFrame ? 0 : (c->lastTicks - c->lastResetTick + 1);
+    return PTSS_OK;
+}
+
+int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
+    if (!c || !out || !n) return fail(PTSS_EINVAL, "null argument");
+    const int numIterations = c->usePathTracer ? (int)c->maxIterations : 1;
+    if (cap < numIterations) return fail(PTSS_ERANGE, "out[] too small");
+    uint32_t tmp[ptss::kMaxBounces + 1];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(tmp, c->dCounts, sizeof(tmp), hipMemcpyDeviceToHost));
+    // a bounce whose input is <= 128 rays did not run (CudaTracer.cu:622): report 0 from there on
+    bool stopped = false;
+    for (int i = 0; i < numIterations; ++i) {
+        if (tmp[i] <= ptss::kMinLiveRays) stopped = true;
+        out[i] = stopped ? 0u : tmp[i];
+    }
+    *n = numIterations;
+    return PTSS_OK;
+}
+
+int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->dTotal, sizeof(*out), hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_bounce_kernel_time(ptss_context* c, double* total_ms, unsigned long long* launches) {
+    if (!c || !total_ms || !launches) return fail(PTSS_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drainKernelEvents(c, true);
+    *total_ms = c->kernelMs;
+    *launches = c->kernelLaunches;
+    c->kernelMs = 0.0;
+    c->kernelLaunches = 0;
+    return PTSS_OK;
+}
+
+}  // extern "C"

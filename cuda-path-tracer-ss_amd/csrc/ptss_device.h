@@ -1,0 +1,84 @@
+// ptss_device.h — device-side data layout shared by the kernels (ptss_kernels.hip) and the
+// context code (ptss_api.hip). See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptmath.h"
+#include "ptss_types.h"
+#include "xorwow.h"
+
+namespace ptss {
+
+// ---- ray pools: struct-of-arrays, one 4-byte plane per field ----------------------------------
+// plane p of a pool starts at pool + p * capacity; capacity = local pixels rounded up to 256.
+enum RayPlane : int {
+    kOx = 0, kOy, kOz,        // origin
+    kDx, kDy, kDz,            // direction
+    kL0x, kL0y, kL0z,         // radiance0 (accumulated)
+    kTx, kTy, kTz,            // radiance1 (throughput)
+    kPix,                     // local pixel index (Ray::pixelOffset)
+    kR0, kR1, kR2, kR3, kR4,  // XORWOW v[0..4]
+    kRd,                      // XORWOW d
+    kRayPlanes                // = 19 planes = 76 B per ray
+};
+constexpr int kRngPlanes = 6;
+constexpr int kMaxBounces = 64;  // counts[] has kMaxBounces + 1 entries
+constexpr int kBlock = 256;
+constexpr uint32_t kMinLiveRays = 128;  // loop guard `numRays > 128`, CudaTracer.cu:622
+
+// ---- scene blob: one contiguous array of float4 staged into LDS by every workgroup --------------
+// (scene records are read by all lanes at the same index -> LDS broadcast reads)
+struct SceneLayout {
+    int numSpheres, numTriangles, numMaterials, numPointLights, numAreaLights;
+    // offsets in float4 units
+    int offSphere;      // S x {cx, cy, cz, radius^2}
+    int offSphereMat;   // ceil(S/4) x 4 ints
+    int offTri;         // T x 3: {v0.xyz, bits(materialIdx)}, {e1.xyz, 0}, {e2.xyz, 0}
+    int offTriNormal;   // T x 3: {n0,0},{n1,0},{n2,0}
+    int offTriVert;     // T x 2: {v1,0},{v2,0}   (area-light sampling)
+    int offMaterial;    // M x 5: {diffuseColor, diffAvg},{specularColor, specAvg},{absorption, refrAvg},
+                        //        {emmitance, roughness},{specularExponent, indexOfRefraction, bits(flags), 0}
+    int offPointLight;  // P x 2: {position,0},{power,0}
+    int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
+    int totalVec4;
+};
+
+struct TileMap {
+    int width, height;      // full frame
+    int localRows;          // rows owned by this context
+    int rank, world, bandRows;
+};
+
+struct EyeParams {  // computeEyeRay constants evaluated once on the host with ptm::tan
+    ptss_camera camera;
+    float s;        // -2 * tan(fov/2)
+    float aspect;   // H / W
+    float invW, invH;
+};
+
+struct FrameBuffers {
+    float* pool[2];          // ray pools (ping-pong), kRayPlanes planes each
+    uint32_t* rngHome;       // kRngPlanes planes, per local pixel: where a pixel's stream rests between paths
+    uint32_t* counts;        // [kMaxBounces + 1] rays entering bounce b of the current frame
+    unsigned long long* totalRayBounces;
+    uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
+    float* fsum;             // float3 per local pixel or nullptr
+    ptss_uchar4* pixels;     // display buffer or nullptr
+    uint32_t capacity;       // plane stride
+    uint32_t numPixels;      // local pixels
+    float inverseTicks;      // 1.f / (ticks - lastResetTick + 1)
+    float defaultColor[3];
+};
+
+// ---- launchers (ptss_kernels.hip) --------------------------------------------------------------
+hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t capacity, TileMap tile, uint64_t seed,
+                         const uint32_t* jumpTable);
+hipError_t launchClear(hipStream_t st, const FrameBuffers& fb);
+hipError_t launchEyeRays(hipStream_t st, const FrameBuffers& fb, TileMap tile, EyeParams eye, int numBounces);
+hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
+                        bool isLast, int gridBlocks);
+hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);
+int bounceOccupancyBlocksPerCU(size_t ldsBytes);
+
+}  // namespace ptss

@@ -1,0 +1,104 @@
+/* ptss.h — C-ABI of libptss.so: the MI355X-native drop-in for the reference's per-frame hot path.
+ *
+ * The reference has no plugin/FFI layer; its seam is the GPUAnimBitmap frame callback plus the
+ * scene vectors. Each entry point below names the reference code it replaces
+ * (paths relative to /root/reference/CudaTracer/). INTEGRATION.md shows the host-side glue.
+ *
+ * Conventions: plain pointers and sizes only; every function returns PTSS_OK (0) or a negative
+ * PTSS_E* code (no exit(), unlike CUDA_ERROR_HANDLE, CudaUtils.h:13-21); no exceptions cross the
+ * boundary; one host thread per context at a time (the reference is single-threaded, CudaUtils.h:117).
+ * There is NO CPU fallback: without a usable HIP device ptss_create fails with PTSS_ENODEVICE.
+ */
+#ifndef PTSS_H
+#define PTSS_H
+
+#include "ptss_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTSS_OK 0
+#define PTSS_EINVAL (-1)   /* bad argument */
+#define PTSS_EHIP (-2)     /* a HIP runtime call or kernel launch failed; see ptss_last_error_detail */
+#define PTSS_ENODEVICE (-3)/* no usable HIP device */
+#define PTSS_ENOMEM (-4)   /* host or device allocation failed */
+#define PTSS_ERANGE (-5)   /* output buffer too small / index out of range */
+
+typedef struct ptss_context ptss_context; /* ≙ ProgramData + RendererData + every cudaMalloc of main() */
+
+typedef struct ptss_render_config {
+    int width, height;           /* full frame; the reference's compile-time DIM x DIM (CudaUtils.h:7) */
+    unsigned long long seed;     /* curand_init seed; the reference passes clock64() (CudaTracer.cu:28) */
+    unsigned int maxIterations;  /* ProgramData::maxIterations, default 15 (CudaTracer.h:39) */
+    int device;                  /* HIP device ordinal (reference: cudaChooseDevice, CudaUtils.h:49-57) */
+    /* Pixel-tile shard (north_star): this context owns the rows y with
+     * (y / bandRows) % tileWorld == tileRank. tileWorld = 1 renders the whole frame. The RNG
+     * subsequence is the GLOBAL pixel index, so the image does not depend on the sharding. */
+    int tileRank, tileWorld, bandRows;
+    int syncEachFrame;     /* 1: block on the stop event and record ms each frame, as CudaTracer.cu:639-642 */
+    int floatAccumulator;  /* 1: also keep a linear float32 sum of radiance0 per pixel */
+    int timeKernels;       /* 1: bracket every bounce kernel with HIP events (bench.py roofline) */
+} ptss_render_config;
+
+/* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */
+int ptss_default_config(ptss_render_config* cfg);
+
+/* ≙ main(): cudaMalloc x8, cudaMemcpy x5 of the scene vectors, ProgramData fill, curandSetupKernel
+ * (CudaTracer.cu:671-724). Scene arrays are copied; the caller may free them afterwards.
+ * Starts with Camera() defaults, usePathTracer = true, resetTicksThisFrame = true (:703,:717). */
+int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, ptss_context** out);
+
+/* ≙ cudaFree x8 + delete data (CudaTracer.cu:731-740). */
+int ptss_destroy(ptss_context* ctx);
+
+/* ≙ generateFrame(uchar4* pixels, void* dataBlock, int ticks) (CudaTracer.cu:587-647), the fAnim
+ * callback of GPUAnimBitmap (CudaUtils.h:36,154). dev_pixels: DEVICE pointer to this context's
+ * local pixels (width * ptss_local_rows, RGBA, row 0 = bottom), owned by the caller, or NULL to
+ * skip the display write. ticks: the caller's running counter (starts at 1, CudaUtils.h:146). */
+int ptss_generate_frame(ptss_context* ctx, ptss_uchar4* dev_pixels, int ticks);
+
+/* ≙ Key()/moveCamera() effects on ProgramData (CudaTracer.cu:782-785): store camera, set the reset flag. */
+int ptss_set_camera(ptss_context* ctx, const ptss_camera* camera);
+int ptss_get_camera(const ptss_context* ctx, ptss_camera* out);
+/* ≙ resetTicksThisFrame = true (CudaTracer.cu:764,784). */
+int ptss_request_reset(ptss_context* ctx);
+/* ≙ space bar: usePathTracer toggle + reset (CudaTracer.cu:760-765). 0 = one-bounce ray tracing. */
+int ptss_set_mode(ptss_context* ctx, int usePathTracer);
+int ptss_set_max_iterations(ptss_context* ctx, unsigned int maxIterations);
+
+/* Plumbing for callers that own device memory / streams (PyTorch, GPUAnimBitmap). */
+int ptss_set_stream(ptss_context* ctx, void* hipStream);            /* default: the null stream */
+int ptss_bind_accumulator(ptss_context* ctx, uint32_t* dev_uint3);  /* external totalPixelColors, 3 u32 per local pixel */
+int ptss_accumulator_devptr(ptss_context* ctx, uint32_t** out);
+int ptss_float_accumulator_devptr(ptss_context* ctx, float** out);
+int ptss_alloc_pixels(ptss_context* ctx, ptss_uchar4** out_dev);    /* headless stand-in for the GL PBO (CudaUtils.h:72-81) */
+int ptss_free_pixels(ptss_context* ctx, ptss_uchar4* dev);
+int ptss_local_pixels(const ptss_context* ctx, size_t* out);        /* width * local rows */
+int ptss_local_rows(const ptss_context* ctx, int* rows, int cap, int* count); /* global y of each local row */
+
+/* Device -> host copies (synchronising). count = number of ELEMENTS of the destination type. */
+int ptss_read_accumulator(ptss_context* ctx, uint32_t* host_uint3, size_t count);       /* 3 * local pixels */
+int ptss_read_float_accumulator(ptss_context* ctx, float* host_float3, size_t count);   /* 3 * local pixels */
+int ptss_read_pixels(ptss_context* ctx, const ptss_uchar4* dev_pixels, ptss_uchar4* host, size_t count);
+int ptss_read_rng_state(ptss_context* ctx, size_t local_pixel, uint32_t* out6);         /* v0..v4, d */
+int ptss_synchronize(ptss_context* ctx);
+
+/* ≙ the "Rays per pixel / Time per pass" line (CudaTracer.cu:641-646). */
+int ptss_last_pass_ms(ptss_context* ctx, float* out_ms);
+int ptss_samples_since_reset(const ptss_context* ctx, int* out);
+/* Rays that ENTERED each bounce of the last frame (numRays at CudaTracer.cu:623); returns count in *n. */
+int ptss_live_counts(ptss_context* ctx, uint32_t* out, int cap, int* n);
+/* Sum over all frames and bounces of rays processed by the bounce kernel (the Mrays numerator). */
+int ptss_total_ray_bounces(ptss_context* ctx, unsigned long long* out);
+/* HIP-event time of the bounce kernel since the last call (needs cfg.timeKernels): total ms, launches. */
+int ptss_bounce_kernel_time(ptss_context* ctx, double* total_ms, unsigned long long* launches);
+
+const char* ptss_error_string(int code);
+const char* ptss_last_error_detail(void);
+int ptss_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
