@@ -6,6 +6,7 @@
 // reference's `numRays > 128` guard itself, so a frame is one uninterrupted stream of launches
 // with at most one event wait at the end (cfg.syncEachFrame, the reference's :639-642).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -67,7 +68,15 @@ struct ptss_context {
     bool usePathTracer = true;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
-    int gridBlocks = 0;
+    int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
+    bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
+    // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
+    uint32_t hint[ptss::kMaxBounces + 1] = {0};
+    bool haveHint = false;
+    uint32_t* hCounts = nullptr;  // pinned, kHintSlots x (kMaxBounces + 1)
+    hipEvent_t hintEvent[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hintPending[4] = {false, false, false, false};
+    unsigned frameIndex = 0;
     // bounce-kernel timing (cfg.timeKernels)
     std::vector<EventPair> evFree, evBusy;
     double kernelMs = 0.0;
@@ -318,14 +327,18 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(e3);
     }
 
-    // persistent-style grid: enough workgroups to fill every CU at the kernel's occupancy, grid-stride beyond
-    hipDeviceProp_t prop;
-    CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-    int perCU = ptss::bounceOccupancyBlocksPerCU(ldsBytes);
-    if (perCU <= 0) perCU = 4;
-    c->gridBlocks = prop.multiProcessorCount * perCU;
-    const int needed = (int)((c->numPixels + ptss::kBlock - 1) / ptss::kBlock);
-    if (c->gridBlocks > needed) c->gridBlocks = needed > 0 ? needed : 1;
+    // Scene access path: staged into LDS (north_star). The scalar-load variant (wave-uniform
+    // s_load through the scalar cache) is kept for A/B runs via PTSS_SCENE_PATH=scalar; on the
+    // 38-primitive "mixed" scene it measured 16 % slower (profiles/README.md, r01).
+    c->sceneInLds = true;
+    if (const char* e = getenv("PTSS_SCENE_PATH")) {
+        if (!strcmp(e, "lds")) c->sceneInLds = true;
+        if (!strcmp(e, "scalar")) c->sceneInLds = false;
+    }
+    c->maxBlocks = (int)((c->numPixels + ptss::kBlock - 1) / ptss::kBlock);
+    if (c->maxBlocks < 1) c->maxBlocks = 1;
+    CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * (ptss::kMaxBounces + 1) * sizeof(uint32_t), hipHostMallocDefault));
+    for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreateWithFlags(&c->hintEvent[k], hipEventDisableTiming));
 #undef CREATE_TRY
 
     *out = c;
@@ -341,6 +354,9 @@ int ptss_destroy(ptss_context* c) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
+    for (int k = 0; k < 4; ++k)
+        if (c->hintEvent[k]) (void)hipEventDestroy(c->hintEvent[k]);
+    if (c->hCounts) (void)hipHostFree(c->hCounts);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     (void)hipFree(c->dScene);
@@ -380,8 +396,26 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     eye.invH = 1.0f / c->tile.height;
     HIP_TRY(ptss::launchEyeRays(st, fb, c->tile, eye, numIterations));  // :614
 
+    // harvest the newest finished live-count readback (never blocks)
+    for (int k = 0; k < 4; ++k) {
+        if (!c->hintPending[k]) continue;
+        if (hipEventQuery(c->hintEvent[k]) == hipSuccess) {
+            memcpy(c->hint, c->hCounts + k * (ptss::kMaxBounces + 1), sizeof(c->hint));
+            c->haveHint = true;
+            c->hintPending[k] = false;
+        }
+    }
+    (void)hipGetLastError();
+
     if (c->cfg.timeKernels) drainKernelEvents(c, false);
     for (int i = 0; i < numIterations; ++i) {  // :622-633, guard evaluated on the device
+        // grid: one tile per workgroup for the expected live count (+1.5 %), never more than the frame;
+        // the kernel grid-strides, so a low hint costs time, not correctness
+        int blocks = c->maxBlocks;
+        if (i > 0 && c->haveHint) {
+            const unsigned long long want = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
+            if (want < (unsigned long long)blocks) blocks = (int)want;
+        }
         EventPair ev{nullptr, nullptr};
         if (c->cfg.timeKernels) {
             if (c->evFree.empty()) {
@@ -397,13 +431,25 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             }
             HIP_TRY(hipEventRecord(ev.a, st));
         }
-        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->gridBlocks));
+        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks));
         if (c->cfg.timeKernels) {
             HIP_TRY(hipEventRecord(ev.b, st));
             c->evBusy.push_back(ev);
         }
     }
     HIP_TRY(ptss::launchFlush(st, fb, numIterations));  // :637
+
+    // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
+    if (!c->haveHint || (c->frameIndex & 7u) == 0) {
+        const int k = (int)((c->frameIndex >> 3) & 3u);
+        if (!c->hintPending[k]) {
+            HIP_TRY(hipMemcpyAsync(c->hCounts + k * (ptss::kMaxBounces + 1), c->dCounts,
+                                   (ptss::kMaxBounces + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(c->hintEvent[k], st));
+            c->hintPending[k] = true;
+        }
+    }
+    c->frameIndex++;
 
     if (c->cfg.syncEachFrame) {  // :639-642
         HIP_TRY(hipEventRecord(c->evStop, st));

@@ -77,8 +77,9 @@ hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t capacity, T
 hipError_t launchClear(hipStream_t st, const FrameBuffers& fb);
 hipError_t launchEyeRays(hipStream_t st, const FrameBuffers& fb, TileMap tile, EyeParams eye, int numBounces);
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, int gridBlocks);
+                        bool isLast, bool sceneInLds, int gridBlocks);
+size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);
-int bounceOccupancyBlocksPerCU(size_t ldsBytes);
+int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds);
 
 }  // namespace ptss

@@ -469,21 +469,36 @@ __global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int 
     storeRay(fb.pool[0], cap, i, r);
 }
 
-template <bool kLast>
+// kSceneInLds = true : the scene blob is staged into LDS once per workgroup and read by broadcast
+//                      (ds_read_b128, same address in every lane).
+// kSceneInLds = false: the blob is read in place through wave-uniform addresses, which hipcc turns
+//                      into scalar loads (s_load_dwordx4 -> SGPR operands, scalar cache); no staging,
+//                      no LDS. Chosen per scene size at context creation (ptss_api.hip).
+template <bool kLast, bool kSceneInLds>
 __global__ __launch_bounds__(kBlock) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
                                                        SceneLayout L, int bounce) {
-    extern __shared__ float4 sc[];
+    extern __shared__ float4 lds[];
     const uint32_t n = fb.counts[bounce];
     if (n <= kMinLiveRays) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
 
-    for (int k = threadIdx.x; k < L.totalVec4; k += kBlock) sc[k] = sceneBlob[k];
-    __syncthreads();
+    // block-level compaction scratch lives behind the scene image (one LDS object, 16-B aligned)
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(lds + (kSceneInLds ? L.totalVec4 : 0));
+    const float4* sc;
+    if constexpr (kSceneInLds) {
+        for (int k = threadIdx.x; k < L.totalVec4; k += kBlock) lds[k] = sceneBlob[k];
+        __syncthreads();
+        sc = lds;
+    } else {
+        sc = sceneBlob;
+    }
 
     const float* __restrict__ in = fb.pool[bounce & 1];
     float* __restrict__ out = fb.pool[(bounce + 1) & 1];
     const uint32_t cap = fb.capacity;
     const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
 
+    // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
@@ -494,15 +509,22 @@ __global__ __launch_bounds__(kBlock) void bounceKernel(FrameBuffers fb, const fl
             alive = ray.active && !kLast;
             if (!alive) finishPath(fb, ray);
         }
-        // stream compaction of the survivors: ballot + lane rank + one atomic per wave
-        const unsigned long long live = __ballot(alive);
-        if (live) {
+        if constexpr (!kLast) {
+            // stream compaction of the survivors: 64-bit ballot + lane rank inside the wave, the four
+            // wave totals combined through LDS, ONE atomic per workgroup on the device-resident counter
+            const unsigned long long live = __ballot(alive);
             const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
-            const int leader = __ffsll((long long)live) - 1;
-            uint32_t slot = 0;
-            if ((int)lane == leader) slot = atomicAdd(&fb.counts[bounce + 1], (uint32_t)__popcll(live));
-            slot = __shfl(slot, leader) + rank;
+            if (lane == 0) scratch[wave] = (uint32_t)__popcll(live);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+                scratch[4] = total ? atomicAdd(&fb.counts[bounce + 1], total) : 0u;
+            }
+            __syncthreads();
+            uint32_t slot = scratch[4] + rank;
+            for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
             if (alive) storeRay(out, cap, slot, ray);
+            __syncthreads();  // scratch is rewritten by the next tile
         }
     }
 }
@@ -550,14 +572,25 @@ hipError_t launchEyeRays(hipStream_t st, const FrameBuffers& fb, TileMap tile, E
     return hipGetLastError();
 }
 
-hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, int gridBlocks) {
-    const size_t lds = (size_t)layout.totalVec4 * sizeof(float4);
-    if (isLast)
-        hipLaunchKernelGGL(bounceKernel<true>, dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce);
-    else
-        hipLaunchKernelGGL(bounceKernel<false>, dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce);
+template <bool kLast, bool kLds>
+static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout,
+                                int bounce, int gridBlocks) {
+    const size_t lds = bounceLdsBytes(layout, kLds);
+    hipLaunchKernelGGL((bounceKernel<kLast, kLds>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce);
     return hipGetLastError();
+}
+
+size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
+    return ((sceneInLds ? (size_t)layout.totalVec4 : 0) + 2) * sizeof(float4);
+}
+
+hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
+                        bool isLast, bool sceneInLds, int gridBlocks) {
+    if (sceneInLds)
+        return isLast ? launchBounceT<true, true>(st, fb, sceneBlob, layout, bounce, gridBlocks)
+                      : launchBounceT<false, true>(st, fb, sceneBlob, layout, bounce, gridBlocks);
+    return isLast ? launchBounceT<true, false>(st, fb, sceneBlob, layout, bounce, gridBlocks)
+                  : launchBounceT<false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks);
 }
 
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
@@ -565,11 +598,12 @@ hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
     return hipGetLastError();
 }
 
-int bounceOccupancyBlocksPerCU(size_t ldsBytes) {
-    int a = 0, b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false>, kBlock, ldsBytes) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bounceKernel<true>, kBlock, ldsBytes) != hipSuccess) b = 0;
-    return a < b ? a : b;
+int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds) {
+    const size_t lds = bounceLdsBytes(layout, sceneInLds);
+    int a = 0;
+    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true>, kBlock, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false>, kBlock, lds);
+    return e == hipSuccess ? a : 0;
 }
 
 }  // namespace ptss

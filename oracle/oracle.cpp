@@ -35,6 +35,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <omp.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -568,6 +570,12 @@ oracle_ctx* oracle_create(const ptss_scene_desc* scene, int width, int height, u
 }
 
 void oracle_destroy(oracle_ctx* c) { delete c; }
+
+// OpenMP team size for every parallel loop of this library (bench.py: the box's CPU share)
+void oracle_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+int oracle_max_threads(void) { return omp_get_max_threads(); }
 
 void oracle_set_camera(oracle_ctx* c, const ptss_camera* cam) {
     c->camera = *cam;

@@ -33,6 +33,8 @@ def lib():
         L.oracle_create.restype = vp
         L.oracle_destroy.argtypes = [vp]
         L.oracle_destroy.restype = None
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_threads.restype = None
         L.oracle_set_camera.argtypes = [vp, C.POINTER(Camera)]
         L.oracle_set_camera.restype = None
         L.oracle_set_mode.argtypes = [vp, C.c_int]
@@ -72,6 +74,26 @@ def lib():
         L.oracle_probe_eye_ray.restype = None
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def cpu_share():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def _f3(v):

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "cuda-path-tracer-ss_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build the native artefacts once if they are missing (hipcc cross-compiles without a GPU)."""
+    import ptss
+    import oracle as oracle_mod
+    missing = [p for p in (ptss.HOST_LIB, ptss.DEVICE_LIB, oracle_mod.LIB) if not os.path.exists(p)]
+    if missing:
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
