@@ -67,13 +67,13 @@ def build_oracle(force=False):
     return out
 
 
-def build_device(force=False):
+def build_device(force=False, defines=(), name="libptss.so"):
     os.makedirs(LIBDIR, exist_ok=True)
-    out = os.path.join(LIBDIR, "libptss.so")
+    out = os.path.join(LIBDIR, name)
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if force or _newer(out, srcs + _headers()):
-        _run([hipcc] + HIP_FLAGS + ["-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
+        _run([hipcc] + HIP_FLAGS + ["-D" + d for d in defines] + ["-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
     return out
 
 

@@ -57,7 +57,9 @@ struct ptss_context {
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
     float* dFsum = nullptr;
-    uint32_t capacity = 0, numPixels = 0;
+    uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
+    uint32_t poolStride = 0, regionCap = 0;  // ray pools: kShards regions of regionCap slots
+    uint32_t* dShardCount0 = nullptr;
     float defaultColor[3] = {0, 0, 0};
     // ProgramData (CudaTracer.h:32-42)
     ptss_camera camera{};
@@ -71,9 +73,9 @@ struct ptss_context {
     int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
-    uint32_t hint[ptss::kMaxBounces + 1] = {0};
+    uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
     bool haveHint = false;
-    uint32_t* hCounts = nullptr;  // pinned, kHintSlots x (kMaxBounces + 1)
+    uint32_t* hCounts = nullptr;  // pinned, 4 slots x kCountWords
     hipEvent_t hintEvent[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hintPending[4] = {false, false, false, false};
     unsigned frameIndex = 0;
@@ -102,6 +104,32 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
     L.totalVec4 = off;
+    {   // kWaves contiguous chunks of the concatenated [spheres | triangles] list, balanced by cost
+        // (a triangle test costs about three sphere rejections)
+        const int costS = 1, costT = 3;
+        const long total = (long)L.numSpheres * costS + (long)L.numTriangles * costT;
+        int si = 0, ti = 0;
+        long acc = 0;
+        L.chunkSphere[0] = 0;
+        L.chunkTri[0] = 0;
+        for (int c = 1; c <= ptss::kWaves; ++c) {
+            const long target = total * c / ptss::kWaves;
+            while (si < L.numSpheres && acc + costS <= target) { acc += costS; ++si; }
+            if (si == L.numSpheres)
+                while (ti < L.numTriangles && acc + costT <= target + (costT - 1)) { acc += costT; ++ti; }
+            if (c == ptss::kWaves) { si = L.numSpheres; ti = L.numTriangles; }
+            L.chunkSphere[c] = si;
+            L.chunkTri[c] = ti;
+        }
+    }
+    auto finite3 = [](const ptss_vec3& v) { return v.x - v.x == 0.0f && v.y - v.y == 0.0f && v.z - v.z == 0.0f; };
+    L.neeSkipSafe = 1;
+    for (size_t i = 0; i < s.numMaterials; ++i)
+        if (!finite3(s.materials[i].diffuseColor) || !(s.materials[i].diffAvg - s.materials[i].diffAvg == 0.0f)) L.neeSkipSafe = 0;
+    for (size_t i = 0; i < s.numPointLights; ++i)
+        if (!finite3(s.pointLights[i].power)) L.neeSkipSafe = 0;
+    for (size_t i = 0; i < s.numAreaLights; ++i)
+        if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
     for (int i = 0; i < L.numSpheres; ++i) {
         const ptss_sphere& sp = s.spheres[i];
@@ -164,11 +192,14 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.pool[1] = c->dPool[1];
     fb.rngHome = c->dRngHome;
     fb.counts = c->dCounts;
+    fb.shardCount0 = c->dShardCount0;
     fb.totalRayBounces = c->dTotal;
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
     fb.pixels = pixels;
-    fb.capacity = c->capacity;
+    fb.capacity = c->poolStride;
+    fb.regionCap = c->regionCap;
+    fb.homeStride = c->capacity;
     fb.numPixels = c->numPixels;
     fb.inverseTicks = 1.f / (sample + 1);  // CudaTracer.cu:94
     fb.defaultColor[0] = c->defaultColor[0];
@@ -275,11 +306,23 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     c->numPixels = (uint32_t)cfg->width * (uint32_t)localRows;
     c->capacity = ((c->numPixels + 255u) / 256u) * 256u;
     if (c->capacity == 0) c->capacity = 256;
+    uint32_t shardCount0[ptss::kShards] = {0};
+    {
+        const uint32_t tiles = (c->numPixels + ptss::kBlock - 1) / ptss::kBlock;
+        const uint32_t tilesPerShard = (tiles + ptss::kShards - 1) / ptss::kShards;
+        c->regionCap = (tilesPerShard ? tilesPerShard : 1) * ptss::kBlock;
+        c->poolStride = c->regionCap * ptss::kShards;
+        for (uint32_t t = 0; t < tiles; ++t) {
+            const uint32_t first = t * ptss::kBlock;
+            const uint32_t cnt = c->numPixels - first < (uint32_t)ptss::kBlock ? c->numPixels - first : (uint32_t)ptss::kBlock;
+            shardCount0[t % ptss::kShards] += cnt;
+        }
+    }
 
     std::vector<float4> blob;
     packScene(*scene, c->layout, blob);
     const size_t ldsBytes = (size_t)c->layout.totalVec4 * sizeof(float4);
-    if (ldsBytes > 150 * 1024) {
+    if (ptss::bounceLdsBytes(c->layout, true) > 160 * 1024) {
         delete c;
         return fail(PTSS_EINVAL, "scene does not fit the 160 KiB LDS staging budget");
     }
@@ -296,12 +339,14 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
 
     CREATE_TRY(hipMalloc(&c->dScene, blob.size() * sizeof(float4)));
     CREATE_TRY(hipMemcpy(c->dScene, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
-    const size_t poolBytes = (size_t)ptss::kRayPlanes * c->capacity * sizeof(float);
+    const size_t poolBytes = (size_t)ptss::kRayPlanes * c->poolStride * sizeof(float);
     CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
     CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
     CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kRngPlanes * c->capacity * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&c->dCounts, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(c->dCounts, 0, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dCounts, ptss::kCountWords * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->dCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dShardCount0, sizeof(shardCount0)));
+    CREATE_TRY(hipMemcpy(c->dShardCount0, shardCount0, sizeof(shardCount0), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&c->dTotal, sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->dTotal, 0, sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&c->dAccumOwned, (size_t)3 * c->capacity * sizeof(uint32_t)));
@@ -335,9 +380,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         if (!strcmp(e, "lds")) c->sceneInLds = true;
         if (!strcmp(e, "scalar")) c->sceneInLds = false;
     }
-    c->maxBlocks = (int)((c->numPixels + ptss::kBlock - 1) / ptss::kBlock);
-    if (c->maxBlocks < 1) c->maxBlocks = 1;
-    CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * (ptss::kMaxBounces + 1) * sizeof(uint32_t), hipHostMallocDefault));
+    c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
+    CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * ptss::kCountWords * sizeof(uint32_t), hipHostMallocDefault));
     for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreateWithFlags(&c->hintEvent[k], hipEventDisableTiming));
 #undef CREATE_TRY
 
@@ -364,6 +408,7 @@ int ptss_destroy(ptss_context* c) {
     (void)hipFree(c->dPool[1]);
     (void)hipFree(c->dRngHome);
     (void)hipFree(c->dCounts);
+    (void)hipFree(c->dShardCount0);
     (void)hipFree(c->dTotal);
     (void)hipFree(c->dAccumOwned);
     (void)hipFree(c->dFsum);
@@ -400,7 +445,15 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     for (int k = 0; k < 4; ++k) {
         if (!c->hintPending[k]) continue;
         if (hipEventQuery(c->hintEvent[k]) == hipSuccess) {
-            memcpy(c->hint, c->hCounts + k * (ptss::kMaxBounces + 1), sizeof(c->hint));
+            const uint32_t* src = c->hCounts + (size_t)k * ptss::kCountWords;
+            for (int b = 0; b <= ptss::kMaxBounces; ++b) {
+                uint32_t mx = 0;
+                for (int s = 0; s < ptss::kShards; ++s) {
+                    const uint32_t v = src[ptss::countIndex(b, s)];
+                    if (v > mx) mx = v;
+                }
+                c->hint[b] = mx;
+            }
             c->haveHint = true;
             c->hintPending[k] = false;
         }
@@ -413,7 +466,9 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         // the kernel grid-strides, so a low hint costs time, not correctness
         int blocks = c->maxBlocks;
         if (i > 0 && c->haveHint) {
-            const unsigned long long want = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
+            // tiles for the fullest shard (+1.5 %), times kShards (workgroup b serves shard b % kShards)
+            const unsigned long long tilesPerShard = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
+            const unsigned long long want = tilesPerShard * ptss::kShards;
             if (want < (unsigned long long)blocks) blocks = (int)want;
         }
         EventPair ev{nullptr, nullptr};
@@ -443,8 +498,8 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     if (!c->haveHint || (c->frameIndex & 7u) == 0) {
         const int k = (int)((c->frameIndex >> 3) & 3u);
         if (!c->hintPending[k]) {
-            HIP_TRY(hipMemcpyAsync(c->hCounts + k * (ptss::kMaxBounces + 1), c->dCounts,
-                                   (ptss::kMaxBounces + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(c->hCounts + (size_t)k * ptss::kCountWords, c->dCounts,
+                                   ptss::kCountWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(c->hintEvent[k], st));
             c->hintPending[k] = true;
         }
@@ -608,14 +663,16 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
     if (!c || !out || !n) return fail(PTSS_EINVAL, "null argument");
     const int numIterations = c->usePathTracer ? (int)c->maxIterations : 1;
     if (cap < numIterations) return fail(PTSS_ERANGE, "out[] too small");
-    uint32_t tmp[ptss::kMaxBounces + 1];
+    std::vector<uint32_t> raw(ptss::kCountWords);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(tmp, c->dCounts, sizeof(tmp), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(raw.data(), c->dCounts, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     // a bounce whose input is <= 128 rays did not run (CudaTracer.cu:622): report 0 from there on
     bool stopped = false;
     for (int i = 0; i < numIterations; ++i) {
-        if (tmp[i] <= ptss::kMinLiveRays) stopped = true;
-        out[i] = stopped ? 0u : tmp[i];
+        uint32_t total = 0;
+        for (int s = 0; s < ptss::kShards; ++s) total += raw[ptss::countIndex(i, s)];
+        if (total <= ptss::kMinLiveRays) stopped = true;
+        out[i] = stopped ? 0u : total;
     }
     *n = numIterations;
     return PTSS_OK;

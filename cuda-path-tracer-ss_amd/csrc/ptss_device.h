@@ -11,7 +11,12 @@
 namespace ptss {
 
 // ---- ray pools: struct-of-arrays, one 4-byte plane per field ----------------------------------
-// plane p of a pool starts at pool + p * capacity; capacity = local pixels rounded up to 256.
+// plane p of a pool starts at pool + p * capacity. A pool is cut into kShards equal regions of
+// regionCap slots; the workgroups with blockIdx % kShards == s read and write region s only and
+// own the s-th live-ray counter, so the compaction atomics of one launch are spread over kShards
+// addresses (one address sustains only ~88 returning atomics/us on MI355X — measured: a single
+// counter was a 45 ps/ray serial floor, profiles/README.md). A region's survivors can never
+// outnumber its input, so regionCap = ceil(tiles / kShards) * kBlock always suffices.
 enum RayPlane : int {
     kOx = 0, kOy, kOz,        // origin
     kDx, kDy, kDz,            // direction
@@ -23,8 +28,29 @@ enum RayPlane : int {
     kRayPlanes                // = 19 planes = 76 B per ray
 };
 constexpr int kRngPlanes = 6;
-constexpr int kMaxBounces = 64;  // counts[] has kMaxBounces + 1 entries
-constexpr int kBlock = 256;
+constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entries
+// Build-time tuning knobs (A/B variants are built by tools/build_variants.py; defaults are the shipped ones)
+#ifndef PTSS_BLOCK
+#define PTSS_BLOCK 256
+#endif
+#ifndef PTSS_MINWAVES
+#define PTSS_MINWAVES 1
+#endif
+#ifndef PTSS_ABLATE
+#define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
+#endif
+#ifndef PTSS_QUEUE
+#define PTSS_QUEUE 1
+#endif
+#ifndef PTSS_SHARDS
+#define PTSS_SHARDS 16
+#endif
+constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workgroup
+constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
+constexpr int kCountStride = 32;            // one counter per 128-B line
+constexpr int kCountWords = (kMaxBounces + 1) * kShards * kCountStride;
+__host__ __device__ inline int countIndex(int bounce, int shard) { return (bounce * kShards + shard) * kCountStride; }
+constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kMinLiveRays = 128;  // loop guard `numRays > 128`, CudaTracer.cu:622
 
 // ---- scene blob: one contiguous array of float4 staged into LDS by every workgroup --------------
@@ -42,6 +68,8 @@ struct SceneLayout {
     int offPointLight;  // P x 2: {position,0},{power,0}
     int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
     int totalVec4;
+    int chunkSphere[kWaves + 1], chunkTri[kWaves + 1];  // primitive ranges of the shadow-pass chunks (wave w: [w], [w+1])
+    int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
 };
 
 struct TileMap {
@@ -60,12 +88,15 @@ struct EyeParams {  // computeEyeRay constants evaluated once on the host with p
 struct FrameBuffers {
     float* pool[2];          // ray pools (ping-pong), kRayPlanes planes each
     uint32_t* rngHome;       // kRngPlanes planes, per local pixel: where a pixel's stream rests between paths
-    uint32_t* counts;        // [kMaxBounces + 1] rays entering bounce b of the current frame
+    uint32_t* counts;        // counts[countIndex(b, s)]: rays of shard s entering bounce b of the current frame
+    const uint32_t* shardCount0;  // [kShards] pixels per shard (constant per context): counts of bounce 0
     unsigned long long* totalRayBounces;
     uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
     float* fsum;             // float3 per local pixel or nullptr
     ptss_uchar4* pixels;     // display buffer or nullptr
-    uint32_t capacity;       // plane stride
+    uint32_t capacity;       // pool plane stride = kShards * regionCap
+    uint32_t regionCap;      // slots per shard region
+    uint32_t homeStride;     // plane stride of rngHome
     uint32_t numPixels;      // local pixels
     float inverseTicks;      // 1.f / (ticks - lastResetTick + 1)
     float defaultColor[3];

@@ -10,10 +10,10 @@
 //                                                   CudaTracer.cu:622, :63-104
 //
 // Design: one ray per lane; ray state in SoA planes (coalesced 256-B wave accesses);
-// the whole scene staged once per workgroup into LDS and read by broadcast; live rays are
-// compacted in the same kernel that traces them — 64-bit __ballot + popcount lane rank + one
-// atomic per wave on a device-resident counter, so the host never reads a ray count inside a
-// frame; a ray that ends (miss, absorbed, last bounce) tone-maps and adds its sample into the
+// the whole scene staged once per workgroup into LDS and read by broadcast; shadow rays regrouped
+// densely through an LDS queue; live rays compacted in the same kernel that traces them — 64-bit
+// __ballot + popcount lane rank + one atomic per workgroup on a device-resident counter, so the
+// host never reads a ray count inside a frame; a ray that ends (miss, absorbed, last bounce) tone-maps and adds its sample into the
 // integer accumulator right there and parks its XORWOW state back in the per-pixel home slot.
 // No MFMA: there is no dense contraction in this path.
 //
@@ -126,64 +126,28 @@ __device__ __forceinline__ bool triangleTest(vec3 v0, vec3 e1, vec3 e2, vec3 o, 
     return true;
 }
 
-// ---- lineOfSight, CudaTracer.cu:420-455 (any-hit; order-independent because it returns at the
-// first accepted primitive and no test depends on another). Per-lane early return: the wave leaves
-// the loops as soon as every lane that entered is occluded. ---------------------------------------
-__device__ __forceinline__ bool lineOfSight(const float4* sc, const SceneLayout& L, vec3 normal, vec3 point0,
-                                            vec3 point1, vec3& w_i, float& distance2) {
-    const vec3 offset = point1 - point0;
-    distance2 = dot(offset, offset);
-    float distance = ptm::sqrt(distance2);
-    w_i = offset / distance;
-    const vec3 lo = point0 + (ptm::kRayBump * normal);
-    distance -= 2 * ptm::kRayBump;
+// ---- the any-hit loops of lineOfSight, CudaTracer.cu:437-452: true when some primitive blocks the
+// segment. Order-independent (the reference returns at the first accepted primitive and no test
+// depends on another); each lane leaves as soon as it is occluded. -------------------------------
+__device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, int s0, int s1, int t0, int t1, vec3 lo,
+                                       vec3 w_i, float distance) {
     float t, w0, w1, w2;
-    for (int i = 0; i < L.numSpheres; ++i)
-        if (sphereTest(sc[L.offSphere + i], lo, w_i, distance, t)) return false;
-    for (int i = 0; i < L.numTriangles; ++i) {
+    for (int i = s0; i < s1; ++i)
+        if (sphereTest(sc[L.offSphere + i], lo, w_i, distance, t)) return true;
+    for (int i = t0; i < t1; ++i) {
         const float4* tr = sc + L.offTri + 3 * i;
-        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), lo, w_i, distance, t, w0, w1, w2)) return false;
+        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), lo, w_i, distance, t, w0, w1, w2)) return true;
     }
-    return true;
+    return false;
 }
 
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
-__device__ __forceinline__ void addLambertTerm(vec3& radiance, vec3 normal, vec3 w_i, vec3 power, float distance2,
+__device__ __forceinline__ void addLambertTerm(vec3& radiance, float cosI, vec3 power, float distance2,
                                                float4 diffuse /* colour, diffAvg */) {
     const vec3 L_i = power / (float)(4 * ptm::kPi * distance2);
-    const float cosI = ptm::max(0.0f, dot(normal, w_i));
     radiance.x += cosI * L_i.x * diffuse.x * diffuse.w * ptm::kInvPi;
     radiance.y += cosI * L_i.y * diffuse.y * diffuse.w * ptm::kInvPi;
     radiance.z += cosI * L_i.z * diffuse.z * diffuse.w * ptm::kInvPi;
-}
-
-// ---- shade, CudaTracer.cu:345-390 + getAreaLightPoint :392-418 --------------------------------
-__device__ __forceinline__ vec3 shade(const float4* sc, const SceneLayout& L, vec3 point, vec3 normal, float4 diffuse,
-                                      ptrng::State& rng) {
-    vec3 radiance = v3(0, 0, 0);
-    vec3 w_i;
-    float distance2;
-    for (int i = 0; i < L.numPointLights; ++i) {
-        const float4 pos = sc[L.offPointLight + 2 * i], pw = sc[L.offPointLight + 2 * i + 1];
-        if (lineOfSight(sc, L, normal, point, xyz(pos), w_i, distance2))
-            addLambertTerm(radiance, normal, w_i, xyz(pw), distance2, diffuse);
-    }
-    for (int i = 0; i < L.numAreaLights; ++i) {
-        const float4 light = sc[L.offAreaLight + i];
-        const float u1 = ptrng::uniform(rng);
-        const float u2 = ptrng::uniform(rng);
-        const float u3 = ptrng::uniform(rng);
-        const float inverseTotal = 1 / (u1 + u2 + u3);
-        const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
-        const int tri = (int)asU(light.w) + ((ptrng::uniform(rng) > .5f) ? 0 : 1);
-        const vec3 a = xyz(sc[L.offTri + 3 * tri]);
-        const vec3 b = xyz(sc[L.offTriVert + 2 * tri]);
-        const vec3 c = xyz(sc[L.offTriVert + 2 * tri + 1]);
-        const vec3 lightPoint = (a * weight0 + b * weight1) + c * weight2;
-        if (lineOfSight(sc, L, normal, point, lightPoint, w_i, distance2))
-            addLambertTerm(radiance, normal, w_i, xyz(light), distance2, diffuse);
-    }
-    return radiance;
 }
 
 // CudaTracer.cu:579-585
@@ -337,7 +301,7 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
         fs[1] += r.L0.y;
         fs[2] += r.L0.z;
     }
-    const uint32_t cap = fb.capacity;
+    const uint32_t cap = fb.homeStride;
     fb.rngHome[0 * cap + p] = r.rng.v[0];
     fb.rngHome[1 * cap + p] = r.rng.v[1];
     fb.rngHome[2 * cap + p] = r.rng.v[2];
@@ -346,72 +310,51 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
     fb.rngHome[5 * cap + p] = r.rng.d;
 }
 
-// ---- one thread of pathTraceKernel, CudaTracer.cu:106-206 -------------------------------------
-template <bool kLast>
-__device__ __forceinline__ void traceOne(const float4* sc, const SceneLayout& L, const FrameBuffers& fb, RayRegs& ray) {
-    float distance = ptm::inf();
-    int hitKind = 0, hitIdx = 0;  // 1 sphere, 2 triangle
-    float w0 = 0, w1 = 0, w2 = 0;
+// ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
+struct Hit {
+    float distance;
+    int kind, idx;  // kind: 0 none, 1 sphere, 2 triangle
+    float w0, w1, w2;
+};
 
+__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d) {
+    Hit h;
+    h.distance = ptm::inf();
+    h.kind = 0;
+    h.idx = 0;
+    h.w0 = h.w1 = h.w2 = 0;
     for (int i = 0; i < L.numSpheres; ++i) {
         float t;
-        if (sphereTest(sc[L.offSphere + i], ray.o, ray.d, distance, t)) {
-            distance = t;
-            hitKind = 1;
-            hitIdx = i;
+        if (sphereTest(sc[L.offSphere + i], o, d, h.distance, t)) {
+            h.distance = t;
+            h.kind = 1;
+            h.idx = i;
         }
     }
     for (int i = 0; i < L.numTriangles; ++i) {
         const float4* tr = sc + L.offTri + 3 * i;
         float t, a0, a1, a2;
-        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), ray.o, ray.d, distance, t, a0, a1, a2)) {
-            distance = t;
-            hitKind = 2;
-            hitIdx = i;
-            w0 = a0;
-            w1 = a1;
-            w2 = a2;
+        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, h.distance, t, a0, a1, a2)) {
+            h.distance = t;
+            h.kind = 2;
+            h.idx = i;
+            h.w0 = a0;
+            h.w1 = a1;
+            h.w2 = a2;
         }
     }
-
-    if (hitKind == 0) {  // :193-198
-        const vec3 dc = v3(fb.defaultColor[0], fb.defaultColor[1], fb.defaultColor[2]);
-        ray.L0 = ray.L0 + dc * ray.T;
-        ray.active = false;
-        return;
-    }
-
-    // surfel of the winning primitive (Primitives.h:69-77, :98-105)
-    const vec3 point = ray.o + ray.d * distance;
-    vec3 normal;
-    int materialIdx;
-    if (hitKind == 1) {
-        const float4 sp = sc[L.offSphere + hitIdx];
-        normal = normalize(point - xyz(sp));
-        materialIdx = reinterpret_cast<const int*>(sc + L.offSphereMat)[hitIdx];
-    } else {
-        const float4* nn = sc + L.offTriNormal + 3 * hitIdx;
-        normal = (xyz(nn[0]) * w0 + xyz(nn[1]) * w1) + xyz(nn[2]) * w2;
-        materialIdx = (int)asU(sc[L.offTri + 3 * hitIdx].w);
-    }
-
-    const float cosI = dot(-ray.d, normal);
-    const float4* mat = sc + L.offMaterial + 5 * materialIdx;
-
-    vec3 directRadiance = v3(0, 0, 0) + xyz(mat[3]);  // emmitance, :163
-    const bool inside = cosI <= 0.0f;
-    if (!inside) directRadiance = directRadiance + shade(sc, L, point, normal, mat[0], ray.rng);
-
-    vec3 indirectRadiance = v3(1, 1, 1);
-    if (!kLast) indirectRadiance = scatter(mat, ray, point, normal, cosI);
-
-    if (inside) {  // Beer-Lambert, :179-185
-        const float4 ab = mat[2];
-        ray.T = ray.T * v3(ptm::exp(-distance * ab.x), ptm::exp(-distance * ab.y), ptm::exp(-distance * ab.z));
-    }
-    ray.L0 = ray.L0 + ray.T * directRadiance;
-    ray.T = ray.T * indirectRadiance;
+    return h;
 }
+
+// LDS work area behind the scene image: compaction scratch + the workgroup's shadow-ray queue.
+constexpr int kQueuePlanes = 7;  // lo.xyz, w_i.xyz, max distance
+struct BlockLds {
+    uint32_t* scratch;   // [0..kWaves) wave totals, [8] block base, [10],[11] queue counters (ping-pong)
+    float* queue;        // kQueuePlanes planes of kBlock floats
+    uint32_t* owner;     // thread that asked
+    uint32_t* occluded;  // per thread: answer
+};
+constexpr int kBlockLdsVec4 = 4 + (kQueuePlanes * kBlock + 2 * kBlock) / 4;
 
 }  // namespace
 
@@ -444,16 +387,16 @@ __global__ void clearKernel(FrameBuffers fb) {
 
 __global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int numBounces) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        fb.counts[0] = fb.numPixels;
-        for (int b = 1; b <= numBounces; ++b) fb.counts[b] = 0;
+    if (i < (uint32_t)kShards) {  // this frame's live-ray counters: bounce 0 = the shard's pixels, the rest 0
+        fb.counts[countIndex(0, (int)i)] = fb.shardCount0[i];
+        for (int b = 1; b <= numBounces; ++b) fb.counts[countIndex(b, (int)i)] = 0;
     }
     if (i >= fb.numPixels) return;
     const PixelCoord pc = locate(tile, i);
-    const uint32_t cap = fb.capacity;
+    const uint32_t hs = fb.homeStride;
     RayRegs r;
-    for (int k = 0; k < 5; ++k) r.rng.v[k] = fb.rngHome[k * cap + i];
-    r.rng.d = fb.rngHome[5 * cap + i];
+    for (int k = 0; k < 5; ++k) r.rng.v[k] = fb.rngHome[k * hs + i];
+    r.rng.d = fb.rngHome[5 * hs + i];
 
     const float jitteredX = pc.x + ptrng::uniform(r.rng);
     const float jitteredY = pc.gy + ptrng::uniform(r.rng);
@@ -466,89 +409,269 @@ __global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int 
     r.T = v3(1, 1, 1);
     r.pix = i;
     r.active = true;
-    storeRay(fb.pool[0], cap, i, r);
+    // tile t of the frame goes to shard t % kShards, as that shard's tile t / kShards
+    const uint32_t t = i / kBlock;
+    const uint32_t slot = (t % kShards) * fb.regionCap + (t / kShards) * kBlock + (i % kBlock);
+    storeRay(fb.pool[0], fb.capacity, slot, r);
 }
 
 // kSceneInLds = true : the scene blob is staged into LDS once per workgroup and read by broadcast
-//                      (ds_read_b128, same address in every lane).
-// kSceneInLds = false: the blob is read in place through wave-uniform addresses, which hipcc turns
-//                      into scalar loads (s_load_dwordx4 -> SGPR operands, scalar cache); no staging,
-//                      no LDS. Chosen per scene size at context creation (ptss_api.hip).
+//                      (ds_read, same address in every lane).
+// kSceneInLds = false: the blob is read in place through wave-uniform addresses (scalar loads);
+//                      A/B switch only (PTSS_SCENE_PATH=scalar).
+//
+// One tile = 256 rays = one workgroup pass, in five steps:
+//   1. load ray, closest hit over all primitives (uniform loops, no divergence), surfel, emission;
+//   2. next-event estimation, one light at a time: every lane that hit a front face draws the
+//      light sample (RNG order as the reference), but only lanes whose Lambert term can be non-zero
+//      enqueue a shadow ray in LDS; the workgroup then traces the queue DENSELY (thread k takes
+//      entry k), so the two brute-force any-hit loops run on full waves instead of once per wave
+//      for a handful of lanes;
+//   3. scatter (lobe choice + new direction), Beer-Lambert, radiance update;
+//   4. paths that ended tone-map into the accumulator; 5. survivors are compacted into the next pool.
+//
+// Exactness of the shadow-ray skip (step 2): the reference adds cosI*L_i*diffuseColor*diffAvg/pi
+// when the light is visible. With diffAvg == 0 or cosI == 0 that term is +-0 whenever L_i is finite
+// (distance2 in (0, inf); light powers and diffuse colours are checked finite at ptss_create,
+// SceneLayout::neeSkipSafe), and radiance + (+-0) == radiance, so visibility cannot change the
+// result and the shadow ray is not traced. Every other case runs the literal path.
 template <bool kLast, bool kSceneInLds>
-__global__ __launch_bounds__(kBlock) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
+__global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
                                                        SceneLayout L, int bounce) {
     extern __shared__ float4 lds[];
-    const uint32_t n = fb.counts[bounce];
-    if (n <= kMinLiveRays) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
+    const uint32_t shard = blockIdx.x % kShards;
+    uint32_t liveTotal = 0;
+    for (int s = 0; s < kShards; ++s) liveTotal += fb.counts[countIndex(bounce, s)];
+    if (liveTotal <= kMinLiveRays) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
+    const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays
 
-    // block-level compaction scratch lives behind the scene image (one LDS object, 16-B aligned)
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(lds + (kSceneInLds ? L.totalVec4 : 0));
+    float4* work = lds + (kSceneInLds ? L.totalVec4 : 0);
+    BlockLds B;
+    B.scratch = reinterpret_cast<uint32_t*>(work);
+    B.queue = reinterpret_cast<float*>(work + 4);
+    B.owner = reinterpret_cast<uint32_t*>(B.queue + kQueuePlanes * kBlock);
+    B.occluded = B.owner + kBlock;
+
     const float4* sc;
     if constexpr (kSceneInLds) {
         for (int k = threadIdx.x; k < L.totalVec4; k += kBlock) lds[k] = sceneBlob[k];
-        __syncthreads();
         sc = lds;
     } else {
         sc = sceneBlob;
     }
+    if (threadIdx.x == 0) {
+        B.scratch[10] = 0;
+        B.scratch[11] = 0;
+    }
+    __syncthreads();
 
-    const float* __restrict__ in = fb.pool[bounce & 1];
-    float* __restrict__ out = fb.pool[(bounce + 1) & 1];
     const uint32_t cap = fb.capacity;
+    const float* __restrict__ in = fb.pool[bounce & 1] + shard * fb.regionCap;      // this shard's region
+    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * fb.regionCap;
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6;
+    const int numLights = L.numPointLights + L.numAreaLights;
 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < n; base += (gridDim.x / kShards) * kBlock) {
         const uint32_t i = base + threadIdx.x;
-        bool alive = false;
+        const bool valid = i < n;
+
+        // ---- 1. closest hit + surfel (pathTraceKernel :121-163) -----------------------------------
         RayRegs ray;
-        if (i < n) {
+        Hit h;
+        h.kind = 0;
+        h.distance = 0;
+        vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
+        float cosI = 0;
+        int materialIdx = 0;
+        vec3 directRadiance = v3(0, 0, 0);
+        if (valid) {
             loadRay(in, cap, i, ray);
-            traceOne<kLast>(sc, L, fb, ray);
-            alive = ray.active && !kLast;
-            if (!alive) finishPath(fb, ray);
+#if PTSS_ABLATE & 2
+            h.kind = 2; h.idx = (int)(ray.pix % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x; h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
+#else
+            h = closestHit(sc, L, ray.o, ray.d);
+#endif
+            if (h.kind != 0) {
+                point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
+                if (h.kind == 1) {
+                    normal = normalize(point - xyz(sc[L.offSphere + h.idx]));
+                    materialIdx = reinterpret_cast<const int*>(sc + L.offSphereMat)[h.idx];
+                } else {
+                    const float4* nn = sc + L.offTriNormal + 3 * h.idx;
+                    normal = (xyz(nn[0]) * h.w0 + xyz(nn[1]) * h.w1) + xyz(nn[2]) * h.w2;
+                    materialIdx = (int)asU(sc[L.offTri + 3 * h.idx].w);
+                }
+                cosI = dot(-ray.d, normal);
+                directRadiance = v3(0, 0, 0) + xyz(sc[L.offMaterial + 5 * materialIdx + 3]);  // emmitance, :163
+            }
         }
-        if constexpr (!kLast) {
-            // stream compaction of the survivors: 64-bit ballot + lane rank inside the wave, the four
-            // wave totals combined through LDS, ONE atomic per workgroup on the device-resident counter
-            const unsigned long long live = __ballot(alive);
-            const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
-            if (lane == 0) scratch[wave] = (uint32_t)__popcll(live);
+        const bool hit = valid && h.kind != 0;
+        const bool inside = cosI <= 0.0f;
+        const bool lit = hit && !inside && !(PTSS_ABLATE & 1);  // shade() runs, :166-169
+        const float4* mat = sc + L.offMaterial + 5 * materialIdx;
+
+        // ---- 2. shade(), CudaTracer.cu:345-390, one light at a time through the LDS queue ----------
+        vec3 radiance = v3(0, 0, 0);
+        for (int li = 0; li < numLights; ++li) {
+            uint32_t* qCount = B.scratch + 10 + (li & 1);
+            bool need = false;
+            vec3 w_i = v3(0, 0, 0), power = v3(0, 0, 0);
+            float distance2 = 0, cosL = 0;
+            if (lit) {
+                vec3 lightPoint;
+                if (li < L.numPointLights) {
+                    lightPoint = xyz(sc[L.offPointLight + 2 * li]);
+                    power = xyz(sc[L.offPointLight + 2 * li + 1]);
+                } else {  // getAreaLightPoint :392-418 — four draws whether or not the light ends up visible
+                    const float4 light = sc[L.offAreaLight + (li - L.numPointLights)];
+                    power = xyz(light);
+                    const float u1 = ptrng::uniform(ray.rng);
+                    const float u2 = ptrng::uniform(ray.rng);
+                    const float u3 = ptrng::uniform(ray.rng);
+                    const float inverseTotal = 1 / (u1 + u2 + u3);
+                    const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
+                    const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
+                    const vec3 a = xyz(sc[L.offTri + 3 * tri]);
+                    const vec3 b = xyz(sc[L.offTriVert + 2 * tri]);
+                    const vec3 c = xyz(sc[L.offTriVert + 2 * tri + 1]);
+                    lightPoint = (a * weight0 + b * weight1) + c * weight2;
+                }
+                // head of lineOfSight :423-432
+                const vec3 offset = lightPoint - point;
+                distance2 = dot(offset, offset);
+                float distance = ptm::sqrt(distance2);
+                w_i = offset / distance;
+                cosL = ptm::max(0.0f, dot(normal, w_i));
+                const bool zeroTerm = L.neeSkipSafe && (distance2 > 0.0f) && (distance2 < ptm::inf()) &&
+                                      (cosL == 0.0f || mat[0].w == 0.0f);
+                need = !zeroTerm;
+#if !PTSS_QUEUE
+                if (need) {  // A/B variant: trace the shadow ray in place (per-lane, divergent)
+                    const vec3 lo = point + (ptm::kRayBump * normal);
+                    distance -= 2 * ptm::kRayBump;
+                    if (!anyHit(sc, L, 0, L.numSpheres, 0, L.numTriangles, lo, w_i, distance))
+                        addLambertTerm(radiance, cosL, power, distance2, mat[0]);
+                }
+#else
+                if (need) {
+                    const vec3 lo = point + (ptm::kRayBump * normal);
+                    distance -= 2 * ptm::kRayBump;
+                    // enqueue: one LDS atomic per wave, lane rank by ballot
+                    const unsigned long long m = __ballot(true);
+                    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t slot = 0;
+                    if ((int)lane == leader) slot = atomicAdd(qCount, (uint32_t)__popcll(m));
+                    slot = __shfl(slot, leader) + rank;
+                    B.queue[0 * kBlock + slot] = lo.x;
+                    B.queue[1 * kBlock + slot] = lo.y;
+                    B.queue[2 * kBlock + slot] = lo.z;
+                    B.queue[3 * kBlock + slot] = w_i.x;
+                    B.queue[4 * kBlock + slot] = w_i.y;
+                    B.queue[5 * kBlock + slot] = w_i.z;
+                    B.queue[6 * kBlock + slot] = distance;
+                    B.owner[slot] = threadIdx.x;
+                    B.occluded[threadIdx.x] = 0u;
+                }
+#endif
+            }
+#if PTSS_QUEUE
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-                scratch[4] = total ? atomicAdd(&fb.counts[bounce + 1], total) : 0u;
+            const uint32_t queued = *qCount;
+            if (threadIdx.x == 0) B.scratch[10 + ((li + 1) & 1)] = 0;  // the other counter, idle until the next light
+            // dense pass: wave w tests EVERY queued segment against the w-th quarter of the primitive
+            // list (cost-balanced on the host), so all four waves work and the serial chain per wave is
+            // a quarter of the scene; any chunk that blocks the segment raises the owner's flag
+            for (uint32_t k = lane; k < queued; k += 64) {
+                const vec3 lo = v3(B.queue[0 * kBlock + k], B.queue[1 * kBlock + k], B.queue[2 * kBlock + k]);
+                const vec3 wi = v3(B.queue[3 * kBlock + k], B.queue[4 * kBlock + k], B.queue[5 * kBlock + k]);
+                if (anyHit(sc, L, L.chunkSphere[wave], L.chunkSphere[wave + 1], L.chunkTri[wave], L.chunkTri[wave + 1], lo, wi,
+                           B.queue[6 * kBlock + k]))
+                    B.occluded[B.owner[k]] = 1u;
             }
             __syncthreads();
-            uint32_t slot = scratch[4] + rank;
-            for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
+            if (need && B.occluded[threadIdx.x] == 0u) addLambertTerm(radiance, cosL, power, distance2, mat[0]);
+#endif
+        }
+        if (PTSS_QUEUE && (numLights & 1)) {  // keep the counter parity the same for every tile
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                B.scratch[10] = 0;
+                B.scratch[11] = 0;
+            }
+        }
+
+        // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
+        bool alive = false;
+        if (valid) {
+            if (hit) {
+                if (lit) directRadiance = directRadiance + radiance;
+                vec3 indirectRadiance = v3(1, 1, 1);
+                if (!kLast && !(PTSS_ABLATE & 4)) indirectRadiance = scatter(mat, ray, point, normal, cosI);
+                if (inside) {  // Beer-Lambert, :179-185
+                    const float4 ab = mat[2];
+                    ray.T = ray.T * v3(ptm::exp(-h.distance * ab.x), ptm::exp(-h.distance * ab.y),
+                                       ptm::exp(-h.distance * ab.z));
+                }
+                ray.L0 = ray.L0 + ray.T * directRadiance;
+                ray.T = ray.T * indirectRadiance;
+            } else {  // :193-198
+                const vec3 dc = v3(fb.defaultColor[0], fb.defaultColor[1], fb.defaultColor[2]);
+                ray.L0 = ray.L0 + dc * ray.T;
+                ray.active = false;
+            }
+            alive = ray.active && !kLast;
+            // ---- 4. writeToPixelsKernel for a finished path -------------------------------------
+            if (!alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+        }
+
+        // ---- 5. stream compaction of the survivors (replaces thrust::partition, :629): 64-bit
+        // ballot + lane rank inside the wave, the four wave totals combined through LDS, ONE atomic
+        // per workgroup on the device-resident counter ------------------------------------------
+        if constexpr (!kLast) {
+            const unsigned long long live = __ballot(alive);
+            const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
+            if (lane == 0) B.scratch[wave] = (uint32_t)__popcll(live);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                for (int w = 0; w < kWaves; ++w) total += B.scratch[w];
+                B.scratch[8] = total ? atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], total) : 0u;
+            }
+            __syncthreads();
+            uint32_t slot = B.scratch[8] + rank;
+            for (uint32_t w = 0; w < wave; ++w) slot += B.scratch[w];
             if (alive) storeRay(out, cap, slot, ray);
             __syncthreads();  // scratch is rewritten by the next tile
         }
     }
 }
 
-// After the last launched bounce: tone-map whatever the loop guard left alive (<= 128 rays), and
-// add this frame's ray-bounce total to the running counter.
+// After the last launched bounce: tone-map whatever the loop guard left alive (<= 128 rays in all
+// shards together), and add this frame's ray-bounce total to the running counter.
 __global__ void flushKernel(FrameBuffers fb, int numBounces) {
     int stop = numBounces;
-    for (int b = 0; b < numBounces; ++b)
-        if (fb.counts[b] <= kMinLiveRays) {
+    unsigned long long sum = 0;
+    for (int b = 0; b < numBounces; ++b) {
+        uint32_t total = 0;
+        for (int s = 0; s < kShards; ++s) total += fb.counts[countIndex(b, s)];
+        if (total <= kMinLiveRays) {
             stop = b;
             break;
         }
-    if (threadIdx.x == 0) {
-        unsigned long long sum = 0;
-        for (int b = 0; b < stop; ++b) sum += fb.counts[b];
-        *fb.totalRayBounces += sum;
+        sum += total;
     }
-    const uint32_t n = fb.counts[stop];  // counts[numBounces] == 0 when the last bounce ran
+    if (threadIdx.x == 0) *fb.totalRayBounces += sum;
     const uint32_t i = threadIdx.x;
-    if (i < n) {
-        RayRegs ray;
-        loadRay(fb.pool[stop & 1], fb.capacity, i, ray);
-        finishPath(fb, ray);
+    for (int s = 0; s < kShards; ++s) {
+        const uint32_t n = fb.counts[countIndex(stop, s)];  // all 0 when the last bounce ran
+        if (i < n) {
+            RayRegs ray;
+            loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);
+            finishPath(fb, ray);
+        }
     }
 }
 
@@ -581,7 +704,7 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
 }
 
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
-    return ((sceneInLds ? (size_t)layout.totalVec4 : 0) + 2) * sizeof(float4);
+    return ((sceneInLds ? (size_t)layout.totalVec4 : 0) + kBlockLdsVec4) * sizeof(float4);
 }
 
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,

@@ -18,7 +18,7 @@ from ptss_types import (AreaLight, Camera, Material, PointLight, SceneDesc, Sphe
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.path.join(_HERE, "lib")
 HOST_LIB = os.path.join(LIBDIR, "libptss_host.so")
-DEVICE_LIB = os.path.join(LIBDIR, "libptss.so")
+DEVICE_LIB = os.path.join(LIBDIR, os.environ.get("PTSS_LIBNAME", "libptss.so"))  # PTSS_LIBNAME: A/B variants
 
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)

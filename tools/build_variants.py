@@ -1,0 +1,36 @@
+"""Builds A/B variants of libptss.so (tuning macros of csrc/ptss_device.h) as lib/libptss_<tag>.so.
+Select one at run time with PTSS_LIBNAME=libptss_<tag>.so. Used only for measurements (profiles/)."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("ptss_build", os.path.join(ROOT, "cuda-path-tracer-ss_amd", "build.py"))
+b = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(b)
+
+VARIANTS = {
+    "b128": ["PTSS_BLOCK=128"],
+    "b512": ["PTSS_BLOCK=512"],
+    "noq": ["PTSS_QUEUE=0"],
+    "noq128": ["PTSS_QUEUE=0", "PTSS_BLOCK=128"],
+    "noq64": ["PTSS_QUEUE=0", "PTSS_BLOCK=64"],
+    "w6": ["PTSS_MINWAVES=6"],
+    "w8": ["PTSS_MINWAVES=8"],
+    "noq_s8": ["PTSS_QUEUE=0", "PTSS_SHARDS=8"],
+    "noq_s32": ["PTSS_QUEUE=0", "PTSS_SHARDS=32"],
+    "noq_s64": ["PTSS_QUEUE=0", "PTSS_SHARDS=64"],
+    "noq128_s32": ["PTSS_QUEUE=0", "PTSS_BLOCK=128", "PTSS_SHARDS=32"],
+    "noq64_s64": ["PTSS_QUEUE=0", "PTSS_BLOCK=64", "PTSS_SHARDS=64"],
+    "q128_s32": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
+    # ablations (results are WRONG by construction; timing only)
+    "a1": ["PTSS_QUEUE=0", "PTSS_ABLATE=1"],
+    "a2": ["PTSS_QUEUE=0", "PTSS_ABLATE=2"],
+    "a3": ["PTSS_QUEUE=0", "PTSS_ABLATE=3"],
+    "a7": ["PTSS_QUEUE=0", "PTSS_ABLATE=7"],
+    "a15": ["PTSS_QUEUE=0", "PTSS_ABLATE=15"],
+}
+
+if __name__ == "__main__":
+    for tag in (sys.argv[1:] or VARIANTS):
+        b.build_device(force=True, defines=VARIANTS[tag], name=f"libptss_{tag}.so")
