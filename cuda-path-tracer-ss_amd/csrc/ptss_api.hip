@@ -104,24 +104,6 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
     L.totalVec4 = off;
-    {   // kWaves contiguous chunks of the concatenated [spheres | triangles] list, balanced by cost
-        // (a triangle test costs about three sphere rejections)
-        const int costS = 1, costT = 3;
-        const long total = (long)L.numSpheres * costS + (long)L.numTriangles * costT;
-        int si = 0, ti = 0;
-        long acc = 0;
-        L.chunkSphere[0] = 0;
-        L.chunkTri[0] = 0;
-        for (int c = 1; c <= ptss::kWaves; ++c) {
-            const long target = total * c / ptss::kWaves;
-            while (si < L.numSpheres && acc + costS <= target) { acc += costS; ++si; }
-            if (si == L.numSpheres)
-                while (ti < L.numTriangles && acc + costT <= target + (costT - 1)) { acc += costT; ++ti; }
-            if (c == ptss::kWaves) { si = L.numSpheres; ti = L.numTriangles; }
-            L.chunkSphere[c] = si;
-            L.chunkTri[c] = ti;
-        }
-    }
     auto finite3 = [](const ptss_vec3& v) { return v.x - v.x == 0.0f && v.y - v.y == 0.0f && v.z - v.z == 0.0f; };
     L.neeSkipSafe = 1;
     for (size_t i = 0; i < s.numMaterials; ++i)

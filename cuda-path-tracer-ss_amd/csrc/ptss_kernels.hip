@@ -9,15 +9,18 @@
 //   flushKernel     <- writeToPixelsKernel for rays still alive when the loop guard stops the frame
 //                                                   CudaTracer.cu:622, :63-104
 //
-// Design: one ray per lane; ray state in SoA planes (coalesced 256-B wave accesses);
-// the whole scene staged once per workgroup into LDS and read by broadcast; shadow rays regrouped
-// densely through an LDS queue; live rays compacted in the same kernel that traces them — 64-bit
-// __ballot + popcount lane rank + one atomic per workgroup on a device-resident counter, so the
-// host never reads a ray count inside a frame; a ray that ends (miss, absorbed, last bounce) tone-maps and adds its sample into the
-// integer accumulator right there and parks its XORWOW state back in the per-pixel home slot.
-// No MFMA: there is no dense contraction in this path.
+// Design: one ray per lane; ray state in SoA planes (coalesced 256-B wave accesses),
+// pools cut into kShards regions with one live-ray counter each; the whole scene staged once per
+// workgroup into LDS and read by broadcast; divergence is attacked at WAVE level, without
+// barriers: sphere hits are resolved from per-lane candidate bit masks, and the shadow rays of
+// two lights at a time are regrouped densely through a wave-private LDS queue; live rays are
+// compacted in the kernel that traces them (64-bit ballot + lane rank + one atomic per workgroup
+// on a device-resident counter, so the host never reads a ray count inside a frame); a path that
+// ends tone-maps into the integer accumulator right there and parks its XORWOW state in the
+// per-pixel home slot. No MFMA: there is no dense contraction in this path.
 //
-// Arithmetic mirrors oracle/oracle.cpp operation for operation (ptmath.h; -ffp-contract=off).
+// Arithmetic mirrors oracle/oracle.cpp operation for operation (ptmath.h; -ffp-contract=off);
+// every restructuring below is argued exact where it is made.
 #include "ptss_device.h"
 
 using namespace ptv;
@@ -28,6 +31,8 @@ namespace {
 __device__ __forceinline__ float asF(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t asU(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ vec3 xyz(float4 v) { return vec3{v.x, v.y, v.z}; }
+// orders this wave's LDS traffic for the compiler; within one wave the LDS executes in order
+__device__ __forceinline__ void waveLdsFence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 struct PixelCoord {
     int x, gy;
@@ -82,6 +87,16 @@ __device__ __forceinline__ void storeRay(float* __restrict__ pool, uint32_t cap,
 }
 
 // ---- Sphere::intersectRay, Primitives.h:107-175. sp = {centre, radius^2}. ---------------------
+// Split at the reference's first exit: sphereMayHit is `!(discriminent < 0)` (Primitives.h:117-118),
+// sphereTest is the whole test; both evaluate b, c and the discriminant with the same operations.
+__device__ __forceinline__ bool sphereMayHit(float4 sp, vec3 o, vec3 d) {
+    const vec3 v = o - xyz(sp);
+    const float b = dot(d, v) * 2;
+    const float c = dot(v, v) - sp.w;
+    const float disc = (b * b) - 4 * c;
+    return !(disc < 0);
+}
+
 // Returns the accepted distance in t; `limit` is the running `distance`.
 __device__ __forceinline__ bool sphereTest(float4 sp, vec3 o, vec3 d, float limit, float& t) {
     const vec3 v = o - xyz(sp);
@@ -104,41 +119,131 @@ __device__ __forceinline__ bool sphereTest(float4 sp, vec3 o, vec3 d, float limi
     return true;
 }
 
-// ---- Triangle::intersectRay, Primitives.h:25-83. v0/e1/e2 from the staged scene. ---------------
-__device__ __forceinline__ bool triangleTest(vec3 v0, vec3 e1, vec3 e2, vec3 o, vec3 d, float limit, float& t,
-                                             float& w0, float& w1, float& w2) {
+// ---- Triangle::intersectRay, Primitives.h:25-83, with the per-lane exits replaced by ONE
+// wave-uniform exit: every lane computes det, 1/det and dist (selects instead of divergent
+// branches: no exec-mask bookkeeping, and the straight-line code lets the scheduler overlap the
+// long division chain with the cross products); the barycentric part runs only if some lane of
+// the wave passed both early tests. `live` marks lanes whose result matters. Same operations on
+// the same values as the reference for every lane that the reference would carry that far;
+// lanes it would have dropped compute values that are discarded. -----------------------------------
+struct TriHit {
+    bool hit;
+    float dist, w0, w1, w2;
+};
+
+struct TriRows {  // one staged triangle: {v0, bits(materialIdx)}, {e1, 0}, {e2, 0}
+    float4 a, b, c;
+};
+__device__ __forceinline__ TriRows loadTri(const float4* tr) { return TriRows{tr[0], tr[1], tr[2]}; }
+
+__device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d, float limit, bool live) {
+    const vec3 v0 = xyz(tr.a), e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
-    if (ptm::abs(det) <= 1e-7f) return false;
     const float inverseDet = 1 / det;
     const vec3 s = o - v0;
     const vec3 r = cross(s, e1);
     const float dist = dot(e2, r) * inverseDet;
-    if ((dist <= 0.0f) || (dist > limit)) return false;
-    const float b1 = dot(s, q) * inverseDet;
-    const float b2 = dot(d, r) * inverseDet;
-    const float b0 = 1.0f - (b1 + b2);
-    if ((b0 < 0) || (b1 < 0) || (b2 < 0)) return false;
-    t = dist;
-    w0 = b0;
-    w1 = b1;
-    w2 = b2;
-    return true;
+    const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
+    TriHit h;
+    h.hit = false;
+    h.dist = dist;
+    h.w0 = h.w1 = h.w2 = 0;
+    if (__any(pass)) {
+        const float b1 = dot(s, q) * inverseDet;
+        const float b2 = dot(d, r) * inverseDet;
+        const float b0 = 1.0f - (b1 + b2);
+        h.hit = pass && !((b0 < 0) || (b1 < 0) || (b2 < 0));
+        h.w0 = b0;
+        h.w1 = b1;
+        h.w2 = b2;
+    }
+    return h;
+}
+
+// ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
+// Spheres, 32 at a time: a uniform pass records in a per-lane bit mask which spheres survive the
+// discriminant test; then every lane resolves ITS OWN candidates in index order. A sphere that
+// fails the discriminant test never changes `distance`, so visiting only the candidates, in the
+// same order, accepts exactly what the reference's full loop accepts — but the square-root path
+// runs a few times per lane instead of once per sphere for the whole wave.
+struct Hit {
+    float distance;
+    int kind, idx;  // kind: 0 none, 1 sphere, 2 triangle
+    float w0, w1, w2;
+};
+
+__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live) {
+    Hit h;
+    h.distance = ptm::inf();
+    h.kind = 0;
+    h.idx = 0;
+    h.w0 = h.w1 = h.w2 = 0;
+    for (int base = 0; base < L.numSpheres; base += 32) {
+        const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
+        uint32_t mask = 0;
+        for (int j = 0; j < cnt; ++j)
+            if (sphereMayHit(sc[L.offSphere + base + j], o, d)) mask |= 1u << j;
+        if (!live) mask = 0;
+        while (mask != 0) {
+            const int j = __builtin_ctz(mask);
+            mask &= mask - 1;
+            float t;
+            if (sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t)) {
+                h.distance = t;
+                h.kind = 1;
+                h.idx = base + j;
+            }
+        }
+    }
+    TriRows tcur = loadTri(sc + L.offTri);
+    for (int i = 0; i < L.numTriangles; ++i) {
+        const TriRows tnxt = loadTri(sc + L.offTri + 3 * (i + 1));
+        const TriHit th = triangleTest(tcur, o, d, h.distance, live);
+        tcur = tnxt;
+        if (th.hit) {
+            h.distance = th.dist;
+            h.kind = 2;
+            h.idx = i;
+            h.w0 = th.w0;
+            h.w1 = th.w1;
+            h.w2 = th.w2;
+        }
+    }
+    return h;
 }
 
 // ---- the any-hit loops of lineOfSight, CudaTracer.cu:437-452: true when some primitive blocks the
 // segment. Order-independent (the reference returns at the first accepted primitive and no test
-// depends on another); each lane leaves as soon as it is occluded. -------------------------------
-__device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, int s0, int s1, int t0, int t1, vec3 lo,
-                                       vec3 w_i, float distance) {
-    float t, w0, w1, w2;
-    for (int i = s0; i < s1; ++i)
-        if (sphereTest(sc[L.offSphere + i], lo, w_i, distance, t)) return true;
-    for (int i = t0; i < t1; ++i) {
-        const float4* tr = sc + L.offTri + 3 * i;
-        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), lo, w_i, distance, t, w0, w1, w2)) return true;
+// depends on another). `live`: this lane carries a segment. -----------------------------------------
+__device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance,
+                                       bool live) {
+    bool occluded = false;
+    for (int base = 0; base < L.numSpheres; base += 32) {
+        const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
+        uint32_t mask = 0;
+        for (int j = 0; j < cnt; ++j)
+            if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
+        if (!live || occluded) mask = 0;
+        while (mask != 0) {
+            const int j = __builtin_ctz(mask);
+            mask &= mask - 1;
+            float t;
+            if (sphereTest(sc[L.offSphere + base + j], lo, w_i, distance, t)) {
+                occluded = true;
+                mask = 0;
+            }
+        }
     }
-    return false;
+    TriRows tcur = loadTri(sc + L.offTri);
+    for (int i = 0; i < L.numTriangles; ++i) {
+        if (!__any(live && !occluded)) break;
+        const TriRows tnxt = loadTri(sc + L.offTri + 3 * (i + 1));
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, live && !occluded);
+        tcur = tnxt;
+        occluded = occluded || th.hit;
+    }
+    return occluded;
 }
 
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
@@ -310,51 +415,16 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
     fb.rngHome[5 * cap + p] = r.rng.d;
 }
 
-// ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
-struct Hit {
-    float distance;
-    int kind, idx;  // kind: 0 none, 1 sphere, 2 triangle
-    float w0, w1, w2;
-};
-
-__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d) {
-    Hit h;
-    h.distance = ptm::inf();
-    h.kind = 0;
-    h.idx = 0;
-    h.w0 = h.w1 = h.w2 = 0;
-    for (int i = 0; i < L.numSpheres; ++i) {
-        float t;
-        if (sphereTest(sc[L.offSphere + i], o, d, h.distance, t)) {
-            h.distance = t;
-            h.kind = 1;
-            h.idx = i;
-        }
-    }
-    for (int i = 0; i < L.numTriangles; ++i) {
-        const float4* tr = sc + L.offTri + 3 * i;
-        float t, a0, a1, a2;
-        if (triangleTest(xyz(tr[0]), xyz(tr[1]), xyz(tr[2]), o, d, h.distance, t, a0, a1, a2)) {
-            h.distance = t;
-            h.kind = 2;
-            h.idx = i;
-            h.w0 = a0;
-            h.w1 = a1;
-            h.w2 = a2;
-        }
-    }
-    return h;
-}
-
-// LDS work area behind the scene image: compaction scratch + the workgroup's shadow-ray queue.
-constexpr int kQueuePlanes = 7;  // lo.xyz, w_i.xyz, max distance
-struct BlockLds {
-    uint32_t* scratch;   // [0..kWaves) wave totals, [8] block base, [10],[11] queue counters (ping-pong)
-    float* queue;        // kQueuePlanes planes of kBlock floats
-    uint32_t* owner;     // thread that asked
-    uint32_t* occluded;  // per thread: answer
-};
-constexpr int kBlockLdsVec4 = 4 + (kQueuePlanes * kBlock + 2 * kBlock) / 4;
+// ---- LDS work area behind the scene image -----------------------------------------------------
+// block: [0..kWaves) wave survivor totals, [8] block base in the output region
+// per wave: the shadow-ray queue of one NEE round (kNeeLights lights x 64 lanes):
+//           7 float planes (lo.xyz, w_i.xyz, max distance) + 1 word (owner lane | slot-in-round << 8),
+//           then kNeeLights x 64 answer words.
+constexpr int kNeeLights = 2;                       // lights regrouped per round
+constexpr int kQueueCap = kNeeLights * 64;
+constexpr int kWaveLdsWords = 8 * kQueueCap + kNeeLights * 64;
+constexpr int kBlockScratchVec4 = 4;
+constexpr int kBlockLdsVec4 = kBlockScratchVec4 + (kWaves * kWaveLdsWords + 3) / 4;
 
 }  // namespace
 
@@ -416,28 +486,29 @@ __global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int 
 }
 
 // kSceneInLds = true : the scene blob is staged into LDS once per workgroup and read by broadcast
-//                      (ds_read, same address in every lane).
-// kSceneInLds = false: the blob is read in place through wave-uniform addresses (scalar loads);
+//                      (ds_read, same address in every lane; per-lane gathers in the candidate loops).
+// kSceneInLds = false: the blob is read in place (scalar loads where the address is wave-uniform);
 //                      A/B switch only (PTSS_SCENE_PATH=scalar).
 //
-// One tile = 256 rays = one workgroup pass, in five steps:
-//   1. load ray, closest hit over all primitives (uniform loops, no divergence), surfel, emission;
-//   2. next-event estimation, one light at a time: every lane that hit a front face draws the
-//      light sample (RNG order as the reference), but only lanes whose Lambert term can be non-zero
-//      enqueue a shadow ray in LDS; the workgroup then traces the queue DENSELY (thread k takes
-//      entry k), so the two brute-force any-hit loops run on full waves instead of once per wave
-//      for a handful of lanes;
+// One tile = kBlock rays = one workgroup pass:
+//   1. load ray, closest hit (sphere candidate masks + uniform triangle loop), surfel, emission;
+//   2. next-event estimation, kNeeLights lights per round: every lane that hit a front face draws
+//      the light samples (RNG order as the reference); lanes whose Lambert term can be non-zero
+//      append a shadow segment to their wave's LDS queue; the wave then traces the queue densely
+//      (lane k takes entry k, k+64, ...) and posts the answers back through LDS. No barrier:
+//      producer and consumer are the same wave.
 //   3. scatter (lobe choice + new direction), Beer-Lambert, radiance update;
-//   4. paths that ended tone-map into the accumulator; 5. survivors are compacted into the next pool.
+//   4. paths that ended tone-map into the accumulator; 5. survivors are compacted into the
+//      shard's region of the other pool.
 //
 // Exactness of the shadow-ray skip (step 2): the reference adds cosI*L_i*diffuseColor*diffAvg/pi
 // when the light is visible. With diffAvg == 0 or cosI == 0 that term is +-0 whenever L_i is finite
 // (distance2 in (0, inf); light powers and diffuse colours are checked finite at ptss_create,
 // SceneLayout::neeSkipSafe), and radiance + (+-0) == radiance, so visibility cannot change the
-// result and the shadow ray is not traced. Every other case runs the literal path.
+// result and the segment is not traced. Every other case runs the literal path.
 template <bool kLast, bool kSceneInLds>
 __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
-                                                       SceneLayout L, int bounce) {
+                                                                      SceneLayout L, int bounce) {
     extern __shared__ float4 lds[];
     const uint32_t shard = blockIdx.x % kShards;
     uint32_t liveTotal = 0;
@@ -445,31 +516,26 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
     if (liveTotal <= kMinLiveRays) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays
 
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
     float4* work = lds + (kSceneInLds ? L.totalVec4 : 0);
-    BlockLds B;
-    B.scratch = reinterpret_cast<uint32_t*>(work);
-    B.queue = reinterpret_cast<float*>(work + 4);
-    B.owner = reinterpret_cast<uint32_t*>(B.queue + kQueuePlanes * kBlock);
-    B.occluded = B.owner + kBlock;
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(work);
+    float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
+    uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
+    uint32_t* wqAnswer = wqOwner + kQueueCap;  // [kNeeLights][64]
 
     const float4* sc;
     if constexpr (kSceneInLds) {
         for (int k = threadIdx.x; k < L.totalVec4; k += kBlock) lds[k] = sceneBlob[k];
+        __syncthreads();
         sc = lds;
     } else {
         sc = sceneBlob;
     }
-    if (threadIdx.x == 0) {
-        B.scratch[10] = 0;
-        B.scratch[11] = 0;
-    }
-    __syncthreads();
 
     const uint32_t cap = fb.capacity;
-    const float* __restrict__ in = fb.pool[bounce & 1] + shard * fb.regionCap;      // this shard's region
+    const float* __restrict__ in = fb.pool[bounce & 1] + shard * fb.regionCap;  // this shard's region
     float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * fb.regionCap;
-    const uint32_t lane = __lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
     const int numLights = L.numPointLights + L.numAreaLights;
 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
@@ -479,128 +545,123 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
 
         // ---- 1. closest hit + surfel (pathTraceKernel :121-163) -----------------------------------
         RayRegs ray;
+        ray.o = ray.d = ray.L0 = ray.T = v3(0, 0, 0);
+        ray.pix = 0;
+        ray.active = false;
+        if (valid) loadRay(in, cap, i, ray);
+#if PTSS_ABLATE & 2
         Hit h;
-        h.kind = 0;
-        h.distance = 0;
+        h.kind = 2; h.idx = (int)(ray.pix % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
+        h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
+#else
+        const Hit h = closestHit(sc, L, ray.o, ray.d, valid);
+#endif
+        const bool hit = valid && h.kind != 0;
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
         float cosI = 0;
         int materialIdx = 0;
         vec3 directRadiance = v3(0, 0, 0);
-        if (valid) {
-            loadRay(in, cap, i, ray);
-#if PTSS_ABLATE & 2
-            h.kind = 2; h.idx = (int)(ray.pix % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x; h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
-#else
-            h = closestHit(sc, L, ray.o, ray.d);
-#endif
-            if (h.kind != 0) {
-                point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
-                if (h.kind == 1) {
-                    normal = normalize(point - xyz(sc[L.offSphere + h.idx]));
-                    materialIdx = reinterpret_cast<const int*>(sc + L.offSphereMat)[h.idx];
-                } else {
-                    const float4* nn = sc + L.offTriNormal + 3 * h.idx;
-                    normal = (xyz(nn[0]) * h.w0 + xyz(nn[1]) * h.w1) + xyz(nn[2]) * h.w2;
-                    materialIdx = (int)asU(sc[L.offTri + 3 * h.idx].w);
-                }
-                cosI = dot(-ray.d, normal);
-                directRadiance = v3(0, 0, 0) + xyz(sc[L.offMaterial + 5 * materialIdx + 3]);  // emmitance, :163
+        if (hit) {
+            point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
+            if (h.kind == 1) {
+                normal = normalize(point - xyz(sc[L.offSphere + h.idx]));
+                materialIdx = reinterpret_cast<const int*>(sc + L.offSphereMat)[h.idx];
+            } else {
+                const float4* nn = sc + L.offTriNormal + 3 * h.idx;
+                normal = (xyz(nn[0]) * h.w0 + xyz(nn[1]) * h.w1) + xyz(nn[2]) * h.w2;
+                materialIdx = (int)asU(sc[L.offTri + 3 * h.idx].w);
             }
+            cosI = dot(-ray.d, normal);
+            directRadiance = v3(0, 0, 0) + xyz(sc[L.offMaterial + 5 * materialIdx + 3]);  // emmitance, :163
         }
-        const bool hit = valid && h.kind != 0;
         const bool inside = cosI <= 0.0f;
         const bool lit = hit && !inside && !(PTSS_ABLATE & 1);  // shade() runs, :166-169
         const float4* mat = sc + L.offMaterial + 5 * materialIdx;
 
-        // ---- 2. shade(), CudaTracer.cu:345-390, one light at a time through the LDS queue ----------
+        // ---- 2. shade(), CudaTracer.cu:345-390: kNeeLights lights per round through the wave queue ----
         vec3 radiance = v3(0, 0, 0);
-        for (int li = 0; li < numLights; ++li) {
-            uint32_t* qCount = B.scratch + 10 + (li & 1);
-            bool need = false;
-            vec3 w_i = v3(0, 0, 0), power = v3(0, 0, 0);
-            float distance2 = 0, cosL = 0;
-            if (lit) {
-                vec3 lightPoint;
-                if (li < L.numPointLights) {
-                    lightPoint = xyz(sc[L.offPointLight + 2 * li]);
-                    power = xyz(sc[L.offPointLight + 2 * li + 1]);
-                } else {  // getAreaLightPoint :392-418 — four draws whether or not the light ends up visible
-                    const float4 light = sc[L.offAreaLight + (li - L.numPointLights)];
-                    power = xyz(light);
-                    const float u1 = ptrng::uniform(ray.rng);
-                    const float u2 = ptrng::uniform(ray.rng);
-                    const float u3 = ptrng::uniform(ray.rng);
-                    const float inverseTotal = 1 / (u1 + u2 + u3);
-                    const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
-                    const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
-                    const vec3 a = xyz(sc[L.offTri + 3 * tri]);
-                    const vec3 b = xyz(sc[L.offTriVert + 2 * tri]);
-                    const vec3 c = xyz(sc[L.offTriVert + 2 * tri + 1]);
-                    lightPoint = (a * weight0 + b * weight1) + c * weight2;
-                }
-                // head of lineOfSight :423-432
-                const vec3 offset = lightPoint - point;
-                distance2 = dot(offset, offset);
-                float distance = ptm::sqrt(distance2);
-                w_i = offset / distance;
-                cosL = ptm::max(0.0f, dot(normal, w_i));
-                const bool zeroTerm = L.neeSkipSafe && (distance2 > 0.0f) && (distance2 < ptm::inf()) &&
-                                      (cosL == 0.0f || mat[0].w == 0.0f);
-                need = !zeroTerm;
-#if !PTSS_QUEUE
-                if (need) {  // A/B variant: trace the shadow ray in place (per-lane, divergent)
-                    const vec3 lo = point + (ptm::kRayBump * normal);
+        for (int l0 = 0; l0 < numLights; l0 += kNeeLights) {
+            uint32_t queued = 0;  // wave-uniform
+            bool need[kNeeLights];
+            float cosL[kNeeLights], distance2[kNeeLights];
+#pragma unroll
+            for (int k = 0; k < kNeeLights; ++k) {
+                need[k] = false;
+                cosL[k] = 0;
+                distance2[k] = 0;
+                const int li = l0 + k;
+                if (li >= numLights) continue;  // uniform
+                vec3 lo = v3(0, 0, 0), w_i = v3(0, 0, 0);
+                float distance = 0;
+                if (lit) {
+                    vec3 lightPoint;
+                    if (li < L.numPointLights) {
+                        lightPoint = xyz(sc[L.offPointLight + 2 * li]);
+                    } else {  // getAreaLightPoint :392-418 — four draws whether or not the light ends up visible
+                        const float4 light = sc[L.offAreaLight + (li - L.numPointLights)];
+                        const float u1 = ptrng::uniform(ray.rng);
+                        const float u2 = ptrng::uniform(ray.rng);
+                        const float u3 = ptrng::uniform(ray.rng);
+                        const float inverseTotal = 1 / (u1 + u2 + u3);
+                        const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
+                        const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
+                        const vec3 a = xyz(sc[L.offTri + 3 * tri]);
+                        const vec3 b = xyz(sc[L.offTriVert + 2 * tri]);
+                        const vec3 c = xyz(sc[L.offTriVert + 2 * tri + 1]);
+                        lightPoint = (a * weight0 + b * weight1) + c * weight2;
+                    }
+                    // head of lineOfSight :423-432
+                    const vec3 offset = lightPoint - point;
+                    distance2[k] = dot(offset, offset);
+                    distance = ptm::sqrt(distance2[k]);
+                    w_i = offset / distance;
+                    cosL[k] = ptm::max(0.0f, dot(normal, w_i));
+                    const bool zeroTerm = L.neeSkipSafe && (distance2[k] > 0.0f) && (distance2[k] < ptm::inf()) &&
+                                          (cosL[k] == 0.0f || mat[0].w == 0.0f);
+                    need[k] = !zeroTerm;
+                    lo = point + (ptm::kRayBump * normal);
                     distance -= 2 * ptm::kRayBump;
-                    if (!anyHit(sc, L, 0, L.numSpheres, 0, L.numTriangles, lo, w_i, distance))
-                        addLambertTerm(radiance, cosL, power, distance2, mat[0]);
                 }
-#else
-                if (need) {
-                    const vec3 lo = point + (ptm::kRayBump * normal);
-                    distance -= 2 * ptm::kRayBump;
-                    // enqueue: one LDS atomic per wave, lane rank by ballot
-                    const unsigned long long m = __ballot(true);
-                    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-                    const int leader = __ffsll((long long)m) - 1;
-                    uint32_t slot = 0;
-                    if ((int)lane == leader) slot = atomicAdd(qCount, (uint32_t)__popcll(m));
-                    slot = __shfl(slot, leader) + rank;
-                    B.queue[0 * kBlock + slot] = lo.x;
-                    B.queue[1 * kBlock + slot] = lo.y;
-                    B.queue[2 * kBlock + slot] = lo.z;
-                    B.queue[3 * kBlock + slot] = w_i.x;
-                    B.queue[4 * kBlock + slot] = w_i.y;
-                    B.queue[5 * kBlock + slot] = w_i.z;
-                    B.queue[6 * kBlock + slot] = distance;
-                    B.owner[slot] = threadIdx.x;
-                    B.occluded[threadIdx.x] = 0u;
+                const unsigned long long m = __ballot(need[k]);
+                if (need[k]) {
+                    const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1ull));
+                    wq[0 * kQueueCap + slot] = lo.x;
+                    wq[1 * kQueueCap + slot] = lo.y;
+                    wq[2 * kQueueCap + slot] = lo.z;
+                    wq[3 * kQueueCap + slot] = w_i.x;
+                    wq[4 * kQueueCap + slot] = w_i.y;
+                    wq[5 * kQueueCap + slot] = w_i.z;
+                    wq[6 * kQueueCap + slot] = distance;
+                    wqOwner[slot] = lane | ((uint32_t)k << 8);
+                    wqAnswer[k * 64 + lane] = 0u;
                 }
-#endif
+                queued += (uint32_t)__popcll(m);
             }
-#if PTSS_QUEUE
-            __syncthreads();
-            const uint32_t queued = *qCount;
-            if (threadIdx.x == 0) B.scratch[10 + ((li + 1) & 1)] = 0;  // the other counter, idle until the next light
-            // dense pass: wave w tests EVERY queued segment against the w-th quarter of the primitive
-            // list (cost-balanced on the host), so all four waves work and the serial chain per wave is
-            // a quarter of the scene; any chunk that blocks the segment raises the owner's flag
-            for (uint32_t k = lane; k < queued; k += 64) {
-                const vec3 lo = v3(B.queue[0 * kBlock + k], B.queue[1 * kBlock + k], B.queue[2 * kBlock + k]);
-                const vec3 wi = v3(B.queue[3 * kBlock + k], B.queue[4 * kBlock + k], B.queue[5 * kBlock + k]);
-                if (anyHit(sc, L, L.chunkSphere[wave], L.chunkSphere[wave + 1], L.chunkTri[wave], L.chunkTri[wave + 1], lo, wi,
-                           B.queue[6 * kBlock + k]))
-                    B.occluded[B.owner[k]] = 1u;
+            waveLdsFence();
+            for (uint32_t e0 = 0; e0 < queued; e0 += 64) {  // dense passes over the wave's queue
+                const uint32_t e = e0 + lane;
+                const bool have = e < queued;
+                const uint32_t es = have ? e : 0u;
+                const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
+                const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
+                const bool occ = anyHit(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
+                if (have && occ) {
+                    const uint32_t ow = wqOwner[es];
+                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
+                }
             }
-            __syncthreads();
-            if (need && B.occluded[threadIdx.x] == 0u) addLambertTerm(radiance, cosL, power, distance2, mat[0]);
-#endif
-        }
-        if (PTSS_QUEUE && (numLights & 1)) {  // keep the counter parity the same for every tile
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                B.scratch[10] = 0;
-                B.scratch[11] = 0;
+            waveLdsFence();
+#pragma unroll
+            for (int k = 0; k < kNeeLights; ++k) {
+                const int li = l0 + k;
+                if (li >= numLights) continue;
+                if (need[k] && wqAnswer[k * 64 + lane] == 0u) {
+                    const vec3 power = (li < L.numPointLights) ? xyz(sc[L.offPointLight + 2 * li + 1])
+                                                               : xyz(sc[L.offAreaLight + (li - L.numPointLights)]);
+                    addLambertTerm(radiance, cosL[k], power, distance2[k], mat[0]);
+                }
             }
+            waveLdsFence();
         }
 
         // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
@@ -628,21 +689,21 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
         }
 
         // ---- 5. stream compaction of the survivors (replaces thrust::partition, :629): 64-bit
-        // ballot + lane rank inside the wave, the four wave totals combined through LDS, ONE atomic
-        // per workgroup on the device-resident counter ------------------------------------------
+        // ballot + lane rank inside the wave, the wave totals combined through LDS, ONE atomic per
+        // workgroup on the shard's device-resident counter ---------------------------------------
         if constexpr (!kLast) {
             const unsigned long long live = __ballot(alive);
             const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
-            if (lane == 0) B.scratch[wave] = (uint32_t)__popcll(live);
+            if (lane == 0) scratch[wave] = (uint32_t)__popcll(live);
             __syncthreads();
             if (threadIdx.x == 0) {
                 uint32_t total = 0;
-                for (int w = 0; w < kWaves; ++w) total += B.scratch[w];
-                B.scratch[8] = total ? atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], total) : 0u;
+                for (int w = 0; w < kWaves; ++w) total += scratch[w];
+                scratch[8] = total ? atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], total) : 0u;
             }
             __syncthreads();
-            uint32_t slot = B.scratch[8] + rank;
-            for (uint32_t w = 0; w < wave; ++w) slot += B.scratch[w];
+            uint32_t slot = scratch[8] + rank;
+            for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
             if (alive) storeRay(out, cap, slot, ray);
             __syncthreads();  // scratch is rewritten by the next tile
         }
@@ -652,21 +713,27 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
 // After the last launched bounce: tone-map whatever the loop guard left alive (<= 128 rays in all
 // shards together), and add this frame's ray-bounce total to the running counter.
 __global__ void flushKernel(FrameBuffers fb, int numBounces) {
+    __shared__ uint32_t totals[kMaxBounces + 1];
+    for (int b = threadIdx.x; b <= numBounces; b += blockDim.x) {
+        uint32_t total = 0;
+        for (int s = 0; s < kShards; ++s) total += fb.counts[countIndex(b, s)];
+        totals[b] = total;
+    }
+    __syncthreads();
     int stop = numBounces;
     unsigned long long sum = 0;
     for (int b = 0; b < numBounces; ++b) {
-        uint32_t total = 0;
-        for (int s = 0; s < kShards; ++s) total += fb.counts[countIndex(b, s)];
-        if (total <= kMinLiveRays) {
+        if (totals[b] <= kMinLiveRays) {
             stop = b;
             break;
         }
-        sum += total;
+        sum += totals[b];
     }
     if (threadIdx.x == 0) *fb.totalRayBounces += sum;
+    if (totals[stop] == 0) return;  // the last bounce ran: nothing left alive
     const uint32_t i = threadIdx.x;
     for (int s = 0; s < kShards; ++s) {
-        const uint32_t n = fb.counts[countIndex(stop, s)];  // all 0 when the last bounce ran
+        const uint32_t n = fb.counts[countIndex(stop, s)];
         if (i < n) {
             RayRegs ray;
             loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);

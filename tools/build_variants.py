@@ -10,25 +10,18 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 
 VARIANTS = {
-    "b128": ["PTSS_BLOCK=128"],
-    "b512": ["PTSS_BLOCK=512"],
-    "noq": ["PTSS_QUEUE=0"],
-    "noq128": ["PTSS_QUEUE=0", "PTSS_BLOCK=128"],
-    "noq64": ["PTSS_QUEUE=0", "PTSS_BLOCK=64"],
+    "w1": ["PTSS_MINWAVES=1"],
     "w6": ["PTSS_MINWAVES=6"],
-    "w8": ["PTSS_MINWAVES=8"],
-    "noq_s8": ["PTSS_QUEUE=0", "PTSS_SHARDS=8"],
-    "noq_s32": ["PTSS_QUEUE=0", "PTSS_SHARDS=32"],
-    "noq_s64": ["PTSS_QUEUE=0", "PTSS_SHARDS=64"],
-    "noq128_s32": ["PTSS_QUEUE=0", "PTSS_BLOCK=128", "PTSS_SHARDS=32"],
-    "noq64_s64": ["PTSS_QUEUE=0", "PTSS_BLOCK=64", "PTSS_SHARDS=64"],
-    "q128_s32": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
+    "b128": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
+    "b512": ["PTSS_BLOCK=512"],
+    "s8": ["PTSS_SHARDS=8"],
+    "s32": ["PTSS_SHARDS=32"],
     # ablations (results are WRONG by construction; timing only)
-    "a1": ["PTSS_QUEUE=0", "PTSS_ABLATE=1"],
-    "a2": ["PTSS_QUEUE=0", "PTSS_ABLATE=2"],
-    "a3": ["PTSS_QUEUE=0", "PTSS_ABLATE=3"],
-    "a7": ["PTSS_QUEUE=0", "PTSS_ABLATE=7"],
-    "a15": ["PTSS_QUEUE=0", "PTSS_ABLATE=15"],
+    "a1": ["PTSS_ABLATE=1"],
+    "a2": ["PTSS_ABLATE=2"],
+    "a3": ["PTSS_ABLATE=3"],
+    "a7": ["PTSS_ABLATE=7"],
+    "a15": ["PTSS_ABLATE=15"],
 }
 
 if __name__ == "__main__":
