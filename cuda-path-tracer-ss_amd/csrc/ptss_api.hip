@@ -183,6 +183,10 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.regionCap = c->regionCap;
     fb.homeStride = c->capacity;
     fb.numPixels = c->numPixels;
+    // The reference stops bouncing once <= 128 rays are live IN THE WHOLE FRAME (CudaTracer.cu:622). A
+    // shard cannot know the frame-wide count without a collective per bounce, so a sharded context
+    // never stops early; the two agree whenever the frame-wide count stays above 128.
+    fb.minLive = c->tile.world > 1 ? 0u : ptss::kMinLiveRays;
     fb.inverseTicks = 1.f / (sample + 1);  // CudaTracer.cu:94
     fb.defaultColor[0] = c->defaultColor[0];
     fb.defaultColor[1] = c->defaultColor[1];
@@ -348,7 +352,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         uint32_t* dTable = nullptr;
         CREATE_TRY(hipMalloc(&dTable, table.size() * sizeof(uint32_t)));
         hipError_t e1 = hipMemcpy(dTable, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        hipError_t e2 = e1 == hipSuccess ? ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->tile, cfg->seed, dTable) : e1;
+        hipError_t e2 = e1;
+        if (e1 == hipSuccess && c->numPixels > 0)
+            e2 = ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->tile, cfg->seed, dTable);
         hipError_t e3 = e2 == hipSuccess ? hipDeviceSynchronize() : e2;
         (void)hipFree(dTable);
         CREATE_TRY(e3);
@@ -402,6 +408,12 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     if (!c) return fail(PTSS_EINVAL, "ctx is null");
     hipStream_t st = c->stream;
     c->lastTicks = ticks;
+    if (c->numPixels == 0) {  // a rank whose tile is empty (more ranks than row bands): nothing to render
+        if (c->resetTicksThisFrame) c->lastResetTick = ticks;
+        c->resetTicksThisFrame = false;
+        c->lastMs = 0.0f;
+        return PTSS_OK;
+    }
 
     if (c->resetTicksThisFrame) {  // CudaTracer.cu:602-608
         c->lastResetTick = ticks;
@@ -653,7 +665,7 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
     for (int i = 0; i < numIterations; ++i) {
         uint32_t total = 0;
         for (int s = 0; s < ptss::kShards; ++s) total += raw[ptss::countIndex(i, s)];
-        if (total <= ptss::kMinLiveRays) stopped = true;
+        if (total <= (c->tile.world > 1 ? 0u : ptss::kMinLiveRays)) stopped = true;
         out[i] = stopped ? 0u : total;
     }
     *n = numIterations;

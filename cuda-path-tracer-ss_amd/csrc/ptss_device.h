@@ -94,6 +94,8 @@ struct FrameBuffers {
     uint32_t regionCap;      // slots per shard region
     uint32_t homeStride;     // plane stride of rngHome
     uint32_t numPixels;      // local pixels
+    uint32_t minLive;        // a bounce runs while more than this many rays are live: 128 (CudaTracer.cu:622),
+                             // 0 in a sharded context (the guard is a whole-frame quantity; DESIGN.md "Sharding")
     float inverseTicks;      // 1.f / (ticks - lastResetTick + 1)
     float defaultColor[3];
 };

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
     const uint32_t shard = blockIdx.x % kShards;
     uint32_t liveTotal = 0;
     for (int s = 0; s < kShards; ++s) liveTotal += fb.counts[countIndex(bounce, s)];
-    if (liveTotal <= kMinLiveRays) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
+    if (liveTotal <= fb.minLive) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays
 
     const uint32_t lane = __lane_id();
@@ -723,7 +723,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
     int stop = numBounces;
     unsigned long long sum = 0;
     for (int b = 0; b < numBounces; ++b) {
-        if (totals[b] <= kMinLiveRays) {
+        if (totals[b] <= fb.minLive) {
             stop = b;
             break;
         }

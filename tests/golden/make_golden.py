@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Regenerates the committed golden vectors under tests/golden/ from THIS repo's CPU oracle and
+host scene builder (the reference ships no fixtures and cannot be built here — SURVEY.md §8c).
+
+    python tests/golden/make_golden.py
+
+Outputs (all small):
+  scenes.json          primitive/material/light tables of every preset (float32 values as hex bit patterns)
+  xorwow.json          first 16 raw draws + state for (seed, subsequence) pairs
+  c1_cornell.npz       BASELINE config 1: 256x256 'cornell', 4 bounces: radiance0 of tick 0 (f32),
+                       uint16 accumulator after 16 ticks, display RGB, per-tick live counts
+  c1_default.npz       the code's literal default scene, same size: accumulator, display RGB, live counts
+  small_mixed.npz      96x54 'mixed', 8 bounces, 8 ticks (config 3 materials, non-square), incl. float sums
+"""
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (os.path.join(ROOT, "cuda-path-tracer-ss_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import oracle  # noqa: E402
+import ptss  # noqa: E402
+
+PRESETS = ["default", "cornell", "lambert", "mixed", "pointlight"]
+SEED = 0x5EED
+
+
+def f2hex(x):
+    return struct.pack("<f", x).hex()
+
+
+def hexify(o):
+    if isinstance(o, float):
+        return f2hex(o)
+    if isinstance(o, dict):
+        return {k: hexify(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [hexify(v) for v in o]
+    return o
+
+
+def render(preset, w, h, bounces, ticks, floats=True, rad0_only=False):
+    scene = ptss.Scene(preset)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=SEED)
+    live = []
+    rad0 = None
+    for t in range(ticks):
+        o.generate_frame()
+        live.append(o.live_counts())
+        if t == 0:
+            rad0 = o.last_radiance0()
+    acc = o.accumulator()
+    assert acc.max() < 65536
+    out = dict(accumulator=acc.astype(np.uint16), pixels=o.pixels()[:, :3].copy(),
+               live_counts=np.array(live, dtype=np.uint32),
+               total_ray_bounces=np.array([o.total_ray_bounces()], dtype=np.uint64),
+               meta=np.array([w, h, bounces, ticks, SEED], dtype=np.int64))
+    if floats:
+        out["radiance0_tick0"] = rad0
+        if not rad0_only:
+            out["float_sum"] = o.float_sum()
+    return out
+
+
+def main():
+    scenes = {p: hexify(ptss.Scene(p).table()) for p in PRESETS}
+    stress = ptss.Scene("stress")
+    scenes["stress_summary"] = {"numSpheres": stress.desc.numSpheres, "numTriangles": stress.desc.numTriangles,
+                                "first_sphere": hexify(ptss.Scene("stress").table()["spheres"][0]),
+                                "last_sphere": hexify(ptss.Scene("stress").table()["spheres"][-1])}
+    json.dump(scenes, open(os.path.join(HERE, "scenes.json"), "w"), indent=0, sort_keys=True)
+
+    rng = {}
+    for seed, sub in [(SEED, 0), (SEED, 1), (SEED, 65535), (SEED, 2073599), (0, 0), (0xDEADBEEFCAFE, 12345)]:
+        st, raw, uni = oracle.probe_rng(seed, sub, 16)
+        rng[f"{seed}:{sub}"] = {"state": st.tolist(), "raw": raw.tolist(), "uniform_hex": [f2hex(float(u)) for u in uni]}
+    json.dump(rng, open(os.path.join(HERE, "xorwow.json"), "w"), indent=0, sort_keys=True)
+
+    np.savez_compressed(os.path.join(HERE, "c1_cornell.npz"), **render("cornell", 256, 256, 4, 16, rad0_only=True))
+    np.savez_compressed(os.path.join(HERE, "c1_default.npz"), **render("default", 256, 256, 4, 16, floats=False))
+    np.savez_compressed(os.path.join(HERE, "small_mixed.npz"), **render("mixed", 96, 54, 8, 8))
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

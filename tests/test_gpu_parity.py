@@ -1,6 +1,9 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
 Bit-exact for every integer output (accumulator, display pixels, live counts, RNG state) and for
-the float radiance sums (same IEEE operations on both sides; NaN == NaN)."""
+the float radiance sums (same IEEE operations on both sides; NaN == NaN). The 1e-4 relative
+per-pixel budget of BASELINE.json is therefore met with error 0 — asserted below as well."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +11,8 @@ import oracle
 import ptss
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-4  # north_star: "within 1e-4 relative per pixel under a fixed RNG seed"
 
 
 def _eq_nan(a, b):
@@ -32,6 +37,8 @@ def _run_pair(preset, w, h, bounces, spp, seed=0x5EED, **kw):
     ("mixed", 160, 90, 8, 8),         # config 3 materials, non-square
     ("lambert", 128, 72, 8, 8),       # config 2 materials
     ("pointlight", 96, 96, 5, 6),     # point-light branch of shade()
+    ("default", 64, 64, 15, 4),       # the reference's default maxIterations (CudaTracer.h:39)
+    ("cornell", 33, 17, 6, 5),        # ragged: not a multiple of any tile/wave size
 ])
 def test_frames_match_oracle(preset, w, h, bounces, spp):
     scene, r, o, live = _run_pair(preset, w, h, bounces, spp)
@@ -39,8 +46,66 @@ def test_frames_match_oracle(preset, w, h, bounces, spp):
         assert np.array_equal(lg, lo), f"live counts differ at frame {f}: {lg} vs {lo}"
     assert np.array_equal(r.accumulator(), o.accumulator())
     assert np.array_equal(r.pixels(), o.pixels())
-    assert _eq_nan(r.float_accumulator(), o.float_sum())
+    fg, fo = r.float_accumulator(), o.float_sum()
+    assert _eq_nan(fg, fo)
+    ok = np.isfinite(fo)
+    assert (np.abs(fg[ok] - fo[ok]) <= REL_TOL * np.abs(fo[ok])).all()
     assert r.total_ray_bounces() == o.total_ray_bounces()
     for p in (0, 1, w * h // 2 + 3, w * h - 1):
         assert np.array_equal(r.rng_state(p), o.rng_state(p))
+    r.close()
+
+
+def test_stress_scene_1024_spheres():
+    # config 5's scene (LDS staging of ~21 KB, 32 candidate-mask chunks) at a size the oracle finishes in seconds
+    scene, r, o, live = _run_pair("stress", 48, 32, 5, 2)
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert _eq_nan(r.float_accumulator(), o.float_sum())
+    assert all(np.array_equal(a, b) for a, b in live)
+    r.close()
+
+
+def test_other_seeds_and_many_ticks():
+    scene, r, o, _ = _run_pair("cornell", 40, 40, 4, 40, seed=0xDEADBEEFCAFE)
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    r.close()
+
+
+@pytest.mark.parametrize("name,preset", [("c1_cornell", "cornell"), ("c1_default", "default"), ("small_mixed", "mixed")])
+def test_against_committed_golden_vectors(name, preset):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    w, h, bounces, ticks, seed = [int(x) for x in g["meta"]]
+    r = ptss.Renderer(ptss.Scene(preset), w, h, max_iterations=bounces, seed=seed, float_accumulator=True)
+    live = []
+    for _ in range(ticks):
+        r.generate_frame()
+        live.append(r.live_counts())
+    assert np.array_equal(np.array(live, dtype=np.uint32), g["live_counts"])
+    assert np.array_equal(r.accumulator(), g["accumulator"].astype(np.uint32))
+    assert np.array_equal(r.pixels()[:, :3], g["pixels"])
+    assert r.total_ray_bounces() == int(g["total_ray_bounces"][0])
+    if "float_sum" in g:
+        assert _eq_nan(r.float_accumulator(), g["float_sum"])
+    r.close()
+
+
+def test_loop_guard_leaves_rays_to_the_flush_kernel():
+    # 12x12 = 144 rays: after a bounce or two fewer than 129 are alive and the `numRays > 128` guard
+    # (CudaTracer.cu:622) stops the frame; the survivors must still be tone-mapped (flushKernel)
+    scene, r, o, live = _run_pair("cornell", 12, 12, 8, 6)
+    assert any((lo == 0).any() for _, lo in live), "case does not exercise the guard"
+    assert all(np.array_equal(a, b) for a, b in live)
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    r.close()
+
+
+def test_tiny_frame_below_the_guard():
+    # 8x8 = 64 rays <= 128: no bounce runs at all; every eye ray is written out with radiance 0
+    scene, r, o, live = _run_pair("cornell", 8, 8, 4, 3)
+    assert all((a == 0).all() and np.array_equal(a, b) for a, b in live)
+    assert np.array_equal(r.accumulator(), o.accumulator()) and r.accumulator().max() == 0
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert np.array_equal(r.rng_state(5), o.rng_state(5))
     r.close()

@@ -1,0 +1,102 @@
+"""Host scene builder (cuda-path-tracer-ss_amd/host/Scene.cpp, mirror of the reference's
+CudaTracer/Scene.cpp): structural facts the reference's code implies + the committed primitive tables."""
+import json
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import ptss
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def hexify(o):
+    if isinstance(o, float):
+        return struct.pack("<f", o).hex()
+    if isinstance(o, dict):
+        return {k: hexify(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [hexify(v) for v in o]
+    return o
+
+
+@pytest.mark.parametrize("preset", ["default", "cornell", "lambert", "mixed", "pointlight"])
+def test_tables_match_committed_fixture(preset):
+    want = json.load(open(os.path.join(GOLDEN, "scenes.json")))[preset]
+    assert hexify(ptss.Scene(preset).table()) == want
+
+
+def test_default_scene_counts_and_materials():
+    s = ptss.Scene("default")  # Scene::build, Scene.cpp:17-32; contents SURVEY.md §9.5
+    assert (s.desc.numSpheres, s.desc.numTriangles, s.desc.numMaterials) == (20, 16, 12)
+    assert (s.desc.numAreaLights, s.desc.numPointLights) == (2, 0)
+    m = s.materials
+    for i, rough in zip(range(3), (0.3, 0.1, 0.5)):  # Cook-Torrance, Scene.cpp:198-210
+        assert m[i].flags == bytes([3]) and abs(m[i].roughness - rough) < 1e-7
+        assert abs(m[i].diffAvg - 0.1) < 1e-7 and abs(m[i].specAvg - 0.6) < 1e-7 and abs(m[i].indexOfRefraction - 1.7) < 1e-6
+    for i in range(3, 6):  # glass, Scene.cpp:128-140
+        assert math.isinf(m[i].specularExponent) and abs(m[i].refrAvg - 0.7) < 1e-7 and abs(m[i].indexOfRefraction - 1.55) < 1e-6
+        assert m[i].flags == bytes([0])
+    assert m[10].flags == bytes([1]) and abs(m[10].specAvg - 0.9) < 1e-7 and m[10].roughness == 0.0  # mirror
+    assert m[9].emmitance.tuple() == (1.0, 1.0, 1.0) and abs(m[11].emmitance.y - 0.6) < 1e-7
+    assert [sp.materialIdx for sp in s.spheres] == [i % 3 for i in range(5)] + [3 + i % 3 for i in range(15)]
+    for sp in s.spheres:  # rnd(5)-2.5, rnd(5)-2.5, rnd(7)-9, rnd(1)+.2  (Scene.cpp:161-162)
+        assert -2.5 <= sp.position.x <= 2.5 and -2.5 <= sp.position.y <= 2.5 and -9 <= sp.position.z <= -2
+        assert 0.2 <= sp.radius <= 1.2
+
+
+def test_msvc_rand_sequence_drives_the_spheres():
+    st = 1
+    def rnd():
+        nonlocal st
+        st = (st * 214013 + 2531011) & 0xFFFFFFFF
+        return (st >> 16) & 0x7FFF
+    rnd(); rnd()                                    # two burnt draws (Scene.cpp:217)
+    x = np.float32(5.0) * np.float32(rnd()) / np.float32(32767) - np.float32(2.5)
+    s = ptss.Scene("default")
+    assert s.spheres[0].position.x == x
+
+
+def test_mirror_box_geometry():
+    s = ptss.Scene("default")
+    t = s.triangles
+    fl = t[0]                                       # floor: y = -5, normal +y (up to rotate(90 deg) rounding)
+    for v in (fl.vertex0, fl.vertex1, fl.vertex2):
+        assert abs(v.y + 5) < 1e-5
+    assert abs(fl.normal0.y - 1) < 1e-6 and abs(fl.normal0.x) < 1e-6
+    assert fl.normal0.tuple() == fl.normal1.tuple() == fl.normal2.tuple()
+    for tri in t:                                   # unit flat normals, both triangles of a pair share it
+        n = np.array(tri.normal0.tuple())
+        assert abs(np.linalg.norm(n) - 1) < 1e-6
+    for k in range(0, 16, 2):
+        assert t[k].normal0.tuple() == t[k + 1].normal0.tuple() and t[k].materialIdx == t[k + 1].materialIdx
+        assert t[k].vertex1.tuple() == t[k + 1].vertex1.tuple() and t[k].vertex2.tuple() == t[k + 1].vertex2.tuple()
+    left = t[4]                                     # 88-degree mirror wall pulled in to x = -4 (Scene.cpp:335-339)
+    assert left.materialIdx == 10 and abs(np.mean([left.vertex0.x, left.vertex1.x, left.vertex2.x]) + 4) < 0.2
+    assert [tri.materialIdx for tri in t] == [6, 6, 10, 10, 10, 10, 10, 10, 6, 6, 6, 6, 9, 9, 11, 11]
+    a0, a1 = s.area_lights
+    assert (a0.triangleIdx, a1.triangleIdx) == (12, 14) and a0.numTriangles == 2
+    assert abs(a0.area - 6.25) < 1e-4 and abs(a1.area - 2.25) < 1e-4   # |e1 x e2| of the 2.5^2 / 1.5^2 quads
+    assert np.allclose(a0.power.tuple(), (100, 400, 400)) and np.allclose(a1.power.tuple(), (400 / 3, 0, 400 / 3))
+    assert abs(t[12].vertex0.y - 4.99) < 1e-5 and abs(t[14].vertex0.y + 4.99) < 1e-5
+
+
+def test_cornell_and_presets():
+    c = ptss.Scene("cornell")  # addDefinedSpheres(4) + addCornellBox(8): matches CudaTracer/image.tga
+    assert (c.desc.numSpheres, c.desc.numTriangles, c.desc.numMaterials, c.desc.numAreaLights) == (2, 14, 7, 1)
+    assert c.spheres[0].position.tuple() == (-2.0, -2.5, np.float32(-(4 * 1.3)))
+    assert c.materials[0].specularExponent == 250 and c.materials[1].specularExponent == 300
+    assert c.materials[6].flags == bytes([0])       # Cornell mirror has no PURE_REFLECTION flag (Scene.cpp:247)
+    mixed = ptss.Scene("mixed")
+    assert (mixed.desc.numSpheres, mixed.desc.numTriangles, mixed.desc.numMaterials) == (22, 16, 14)
+    lam = ptss.Scene("lambert")
+    for m in lam.materials:
+        emits = max(m.emmitance.tuple()) > 0
+        assert emits or (abs(m.diffAvg - 0.7) < 1e-7 and m.specAvg == 0 and m.refrAvg == 0)
+    st = ptss.Scene("stress")
+    assert st.desc.numSpheres == 1024 and st.desc.numTriangles == 14
+    with pytest.raises(ptss.PtssError):
+        ptss.Scene("no-such-preset")
