@@ -47,7 +47,7 @@ def cpu_baseline(budget_s=12.0):
     r0 = o.total_ray_bounces()
     t0 = time.perf_counter()
     passes = 0
-    while passes < 2 or (time.perf_counter() - t0 < budget_s and passes < 16):
+    while passes < 2 or (time.perf_counter() - t0 < budget_s and passes < 256):
         o.generate_frame()
         passes += 1
     dt = time.perf_counter() - t0
@@ -88,6 +88,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import tiles
     scene = ptss.Scene(PRESET)
     r = ptss.Renderer(scene, WIDTH, HEIGHT, max_iterations=BOUNCES, seed=SEED, device=local_rank,
                       tile_rank=rank, tile_world=world, band_rows=BAND_ROWS, sync_each_frame=False,
@@ -129,6 +130,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    if rank == 0 and dist is not None:   # untimed sanity: the gathered tiles tile the frame
+        sizes = [len(ptss.tile_rows(HEIGHT, BAND_ROWS, k, world)) * WIDTH for k in range(world)]
+        frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], WIDTH, HEIGHT, BAND_ROWS)
+        assert frame.shape == (WIDTH * HEIGHT, 3) and int(frame.max()) <= 255 * (args.steps + args.warmup)
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
     stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device="cuda")

@@ -119,6 +119,7 @@ class Scene:
         self.preset = preset
         self.desc = SceneDesc()
         host_lib().ptss_scene_describe(self._h, C.byref(self.desc))
+        self.desc._owner = self  # desc borrows the scene's arrays: `Scene(p).desc` must keep the scene alive
 
     def __del__(self):
         if getattr(self, "_h", None) and self._h.value and host_lib is not None:
