@@ -53,13 +53,15 @@ struct ptss_context {
     float* dPool[2] = {nullptr, nullptr};
     uint32_t* dRngHome = nullptr;
     uint32_t* dCounts = nullptr;
-    unsigned long long* dTotal = nullptr;
+    unsigned long long* dTotal = nullptr;   // [0] ray-bounce total, [1..8] diagnostic phase stamps
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
     float* dFsum = nullptr;
     uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
     uint32_t poolStride = 0, regionCap = 0;  // ray pools: kShards regions of regionCap slots
     uint32_t* dShardCount0 = nullptr;
+    uint32_t* dLastCounts = nullptr;   // counts of the frame before (flushKernel's copy)
+    bool cameraDirty = true;           // primary-ray precomputes must be refreshed
     float defaultColor[3] = {0, 0, 0};
     // ProgramData (CudaTracer.h:32-42)
     ptss_camera camera{};
@@ -71,6 +73,7 @@ struct ptss_context {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
     int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
+    int gridCap = 0;             // PTSS_GRID_CAP (measurement only)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
     uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
@@ -103,6 +106,8 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offMaterial = off;    off += 5 * L.numMaterials;
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
+    L.offPrimSphere = off;  off += L.numSpheres;
+    L.offPrimTri = off;     off += 2 * L.numTriangles;
     L.totalVec4 = off;
     auto finite3 = [](const ptss_vec3& v) { return v.x - v.x == 0.0f && v.y - v.y == 0.0f && v.z - v.z == 0.0f; };
     L.neeSkipSafe = 1;
@@ -175,13 +180,14 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.rngHome = c->dRngHome;
     fb.counts = c->dCounts;
     fb.shardCount0 = c->dShardCount0;
+    fb.lastCounts = c->dLastCounts;
     fb.totalRayBounces = c->dTotal;
+    fb.stamps = c->dTotal + 1;
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
     fb.pixels = pixels;
     fb.capacity = c->poolStride;
     fb.regionCap = c->regionCap;
-    fb.homeStride = c->capacity;
     fb.numPixels = c->numPixels;
     // The reference stops bouncing once <= 128 rays are live IN THE WHOLE FRAME (CudaTracer.cu:622). A
     // shard cannot know the frame-wide count without a collective per bounce, so a sharded context
@@ -328,13 +334,17 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     const size_t poolBytes = (size_t)ptss::kRayPlanes * c->poolStride * sizeof(float);
     CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
     CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
-    CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kRngPlanes * c->capacity * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kHomeWords * c->capacity * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&c->dCounts, ptss::kCountWords * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->dCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dLastCounts, ptss::kCountWords * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->dLastCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
+    for (int s = 0; s < ptss::kShards; ++s)  // arm bounce 0 of the first frame (flushKernel re-arms every later one)
+        CREATE_TRY(hipMemcpy(c->dCounts + ptss::countIndex(0, s), &shardCount0[s], sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&c->dShardCount0, sizeof(shardCount0)));
     CREATE_TRY(hipMemcpy(c->dShardCount0, shardCount0, sizeof(shardCount0), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(&c->dTotal, sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(c->dTotal, 0, sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->dTotal, 9 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(c->dTotal, 0, 9 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&c->dAccumOwned, (size_t)3 * c->capacity * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->dAccumOwned, 0, (size_t)3 * c->capacity * sizeof(uint32_t)));
     c->dAccum = c->dAccumOwned;
@@ -369,6 +379,7 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         if (!strcmp(e, "scalar")) c->sceneInLds = false;
     }
     c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
+    if (const char* e = getenv("PTSS_GRID_CAP")) c->gridCap = atoi(e);
     CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * ptss::kCountWords * sizeof(uint32_t), hipHostMallocDefault));
     for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreateWithFlags(&c->hintEvent[k], hipEventDisableTiming));
 #undef CREATE_TRY
@@ -397,6 +408,7 @@ int ptss_destroy(ptss_context* c) {
     (void)hipFree(c->dRngHome);
     (void)hipFree(c->dCounts);
     (void)hipFree(c->dShardCount0);
+    (void)hipFree(c->dLastCounts);
     (void)hipFree(c->dTotal);
     (void)hipFree(c->dAccumOwned);
     (void)hipFree(c->dFsum);
@@ -433,7 +445,10 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     eye.aspect = (float)c->tile.height / (float)c->tile.width;
     eye.invW = 1.0f / c->tile.width;
     eye.invH = 1.0f / c->tile.height;
-    HIP_TRY(ptss::launchEyeRays(st, fb, c->tile, eye, numIterations));  // :614
+    if (c->cameraDirty) {  // origin-only parts of the primary-ray tests (computeEyeRaysKernel :614 itself is fused into bounce 0)
+        HIP_TRY(ptss::launchPrimaryPrep(st, c->dScene, c->layout, c->camera.position));
+        c->cameraDirty = false;
+    }
 
     // harvest the newest finished live-count readback (never blocks)
     for (int k = 0; k < 4; ++k) {
@@ -459,7 +474,9 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         // grid: one tile per workgroup for the expected live count (+1.5 %), never more than the frame;
         // the kernel grid-strides, so a low hint costs time, not correctness
         int blocks = c->maxBlocks;
-        if (i > 0 && c->haveHint) {
+        if (c->gridCap > 0) {  // PTSS_GRID_CAP=<blocks per shard>: measurement knob, persistent-style grids
+            if (c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
+        } else if (i > 0 && c->haveHint) {
             // tiles for the fullest shard (+1.5 %), times kShards (workgroup b serves shard b % kShards)
             const unsigned long long tilesPerShard = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
             const unsigned long long want = tilesPerShard * ptss::kShards;
@@ -480,7 +497,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             }
             HIP_TRY(hipEventRecord(ev.a, st));
         }
-        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks));
+        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks, c->tile, eye));
         if (c->cfg.timeKernels) {
             HIP_TRY(hipEventRecord(ev.b, st));
             c->evBusy.push_back(ev);
@@ -492,7 +509,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     if (!c->haveHint || (c->frameIndex & 7u) == 0) {
         const int k = (int)((c->frameIndex >> 3) & 3u);
         if (!c->hintPending[k]) {
-            HIP_TRY(hipMemcpyAsync(c->hCounts + (size_t)k * ptss::kCountWords, c->dCounts,
+            HIP_TRY(hipMemcpyAsync(c->hCounts + (size_t)k * ptss::kCountWords, c->dLastCounts,
                                    ptss::kCountWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(c->hintEvent[k], st));
             c->hintPending[k] = true;
@@ -511,6 +528,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
 int ptss_set_camera(ptss_context* c, const ptss_camera* camera) {
     if (!c || !camera) return fail(PTSS_EINVAL, "null argument");
     c->camera = *camera;
+    c->cameraDirty = true;
     c->resetTicksThisFrame = true;
     return PTSS_OK;
 }
@@ -635,9 +653,7 @@ int ptss_read_rng_state(ptss_context* c, size_t local_pixel, uint32_t* out6) {
     if (!c || !out6) return fail(PTSS_EINVAL, "null argument");
     if (local_pixel >= c->numPixels) return fail(PTSS_ERANGE, "pixel out of range");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < ptss::kRngPlanes; ++k)
-        HIP_TRY(hipMemcpy(&out6[k], c->dRngHome + (size_t)k * c->capacity + local_pixel, sizeof(uint32_t),
-                          hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out6, c->dRngHome + (size_t)ptss::kHomeWords * local_pixel, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PTSS_OK;
 }
 
@@ -659,7 +675,7 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
     if (cap < numIterations) return fail(PTSS_ERANGE, "out[] too small");
     std::vector<uint32_t> raw(ptss::kCountWords);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(raw.data(), c->dCounts, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(raw.data(), c->dLastCounts, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     // a bounce whose input is <= 128 rays did not run (CudaTracer.cu:622): report 0 from there on
     bool stopped = false;
     for (int i = 0; i < numIterations; ++i) {
@@ -676,6 +692,13 @@ int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
     if (!c || !out) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->dTotal, sizeof(*out), hipMemcpyDeviceToHost));
+    return PTSS_OK;
+}
+
+int ptss_debug_phase_cycles(ptss_context* c, unsigned long long* out8) {
+    if (!c || !out8) return fail(PTSS_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out8, c->dTotal + 1, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTSS_OK;
 }
 

@@ -27,7 +27,7 @@ enum RayPlane : int {
     kRd,                      // XORWOW d
     kRayPlanes                // = 19 planes = 76 B per ray
 };
-constexpr int kRngPlanes = 6;
+constexpr int kHomeWords = 8;     // per-pixel RNG home record: v0..v4, d, 2 pad words (32 B)
 constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entries
 // Build-time tuning knobs (A/B variants are built by tools/build_variants.py; defaults are the shipped ones)
 #ifndef PTSS_BLOCK
@@ -38,6 +38,9 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #endif
 #ifndef PTSS_ABLATE
 #define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
+#endif
+#ifndef PTSS_WAVE_COMPACT
+#define PTSS_WAVE_COMPACT 1   // 1: per-wave compaction, no barriers; 0: per-workgroup (LDS + 2 barriers)
 #endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
@@ -64,6 +67,8 @@ struct SceneLayout {
                         //        {emmitance, roughness},{specularExponent, indexOfRefraction, bits(flags), 0}
     int offPointLight;  // P x 2: {position,0},{power,0}
     int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
+    int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
+    int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}
     int totalVec4;
     int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
 };
@@ -83,16 +88,17 @@ struct EyeParams {  // computeEyeRay constants evaluated once on the host with p
 
 struct FrameBuffers {
     float* pool[2];          // ray pools (ping-pong), kRayPlanes planes each
-    uint32_t* rngHome;       // kRngPlanes planes, per local pixel: where a pixel's stream rests between paths
+    uint32_t* rngHome;       // kHomeWords words per local pixel: where a pixel's stream rests between paths
     uint32_t* counts;        // counts[countIndex(b, s)]: rays of shard s entering bounce b of the current frame
     const uint32_t* shardCount0;  // [kShards] pixels per shard (constant per context): counts of bounce 0
+    uint32_t* lastCounts;    // the previous frame's counts (copied by flushKernel before it re-arms `counts`)
     unsigned long long* totalRayBounces;
+    unsigned long long* stamps;   // [8] wave-cycles per phase, written only by -DPTSS_STAMPS diagnostic builds
     uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
     float* fsum;             // float3 per local pixel or nullptr
     ptss_uchar4* pixels;     // display buffer or nullptr
     uint32_t capacity;       // pool plane stride = kShards * regionCap
     uint32_t regionCap;      // slots per shard region
-    uint32_t homeStride;     // plane stride of rngHome
     uint32_t numPixels;      // local pixels
     uint32_t minLive;        // a bounce runs while more than this many rays are live: 128 (CudaTracer.cu:622),
                              // 0 in a sharded context (the guard is a whole-frame quantity; DESIGN.md "Sharding")
@@ -104,9 +110,9 @@ struct FrameBuffers {
 hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t capacity, TileMap tile, uint64_t seed,
                          const uint32_t* jumpTable);
 hipError_t launchClear(hipStream_t st, const FrameBuffers& fb);
-hipError_t launchEyeRays(hipStream_t st, const FrameBuffers& fb, TileMap tile, EyeParams eye, int numBounces);
+hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayout& layout, ptss_vec3 origin);
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, bool sceneInLds, int gridBlocks);
+                        bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);
 int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds);

@@ -3,7 +3,7 @@
 // Kernels (reference kernels they replace, paths relative to /root/reference/CudaTracer/):
 //   rngInitKernel   <- curandSetupKernel            CudaTracer.cu:22-29
 //   clearKernel     <- clearPixels                  CudaTracer.cu:31-49
-//   eyeRaysKernel   <- computeEyeRaysKernel         CudaTracer.cu:51-61, 321-343
+//   bounceKernel<first> <- computeEyeRaysKernel     CudaTracer.cu:51-61, 321-343 (fused into bounce 0)
 //   bounceKernel    <- pathTraceKernel + thrust::partition + the per-ray part of writeToPixelsKernel
 //                                                   CudaTracer.cu:106-206, :629, :63-104
 //   flushKernel     <- writeToPixelsKernel for rays still alive when the loop guard stops the frame
@@ -161,6 +161,62 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     return h;
 }
 
+// ---- Primary (bounce 0) variants. Every eye ray starts at camera.position, so whatever the tests
+// compute from the ORIGIN and the primitive alone is the same for all lanes and all pixels of a frame:
+//   sphere:   v = o - centre,  c = dot(v,v) - r^2                    (Primitives.h:109,113)
+//   triangle: s = o - v0,  r = cross(s, e1),  dot(e2, r)             (Primitives.h:46-49)
+// primaryPrepKernel evaluates these once per camera with the very same operations; the per-lane work
+// that is left is identical to the generic tests (same values, same order), minus 8 of 15 / 12 of 55
+// instructions.
+__device__ __forceinline__ bool sphereMayHitPrimary(float4 pv /* v, c */, vec3 d) {
+    const float b = dot(d, xyz(pv)) * 2;
+    const float disc = (b * b) - 4 * pv.w;
+    return !(disc < 0);
+}
+
+__device__ __forceinline__ bool sphereTestPrimary(float4 pv, vec3 d, float limit, float& t) {
+    const float b = dot(d, xyz(pv)) * 2;
+    float disc = (b * b) - 4 * pv.w;
+    if (disc < 0) return false;
+    disc = ptm::sqrt(disc);
+    float t0 = (-b + disc) * 0.5f;
+    float t1 = (-b - disc) * 0.5f;
+    if (t0 < 0 && t1 < 0) return false;
+    if (t0 > t1) {
+        const float tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    const float cand = (t0 < 0) ? t1 : t0;
+    if (cand > limit) return false;
+    t = cand;
+    return true;
+}
+
+__device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 ps /* s, dot(e2,r) */, float4 pr /* r */,
+                                                      vec3 d, float limit, bool live) {
+    const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
+    const vec3 q = cross(d, e2);
+    const float det = dot(e1, q);
+    const float inverseDet = 1 / det;
+    const float dist = ps.w * inverseDet;
+    const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
+    TriHit h;
+    h.hit = false;
+    h.dist = dist;
+    h.w0 = h.w1 = h.w2 = 0;
+    if (__any(pass)) {
+        const float b1 = dot(xyz(ps), q) * inverseDet;
+        const float b2 = dot(d, xyz(pr)) * inverseDet;
+        const float b0 = 1.0f - (b1 + b2);
+        h.hit = pass && !((b0 < 0) || (b1 < 0) || (b2 < 0));
+        h.w0 = b0;
+        h.w1 = b1;
+        h.w2 = b2;
+    }
+    return h;
+}
+
 // ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
 // Spheres, 32 at a time: a uniform pass records in a per-lane bit mask which spheres survive the
 // discriminant test; then every lane resolves ITS OWN candidates in index order. A sphere that
@@ -173,6 +229,7 @@ struct Hit {
     float w0, w1, w2;
 };
 
+template <bool kPrimary>
 __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live) {
     Hit h;
     h.distance = ptm::inf();
@@ -182,14 +239,19 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
     for (int base = 0; base < L.numSpheres; base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
         uint32_t mask = 0;
-        for (int j = 0; j < cnt; ++j)
-            if (sphereMayHit(sc[L.offSphere + base + j], o, d)) mask |= 1u << j;
+        for (int j = 0; j < cnt; ++j) {
+            const bool may = kPrimary ? sphereMayHitPrimary(sc[L.offPrimSphere + base + j], d)
+                                      : sphereMayHit(sc[L.offSphere + base + j], o, d);
+            if (may) mask |= 1u << j;
+        }
         if (!live) mask = 0;
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
             float t;
-            if (sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t)) {
+            const bool acc = kPrimary ? sphereTestPrimary(sc[L.offPrimSphere + base + j], d, h.distance, t)
+                                      : sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t);
+            if (acc) {
                 h.distance = t;
                 h.kind = 1;
                 h.idx = base + j;
@@ -199,7 +261,9 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
     TriRows tcur = loadTri(sc + L.offTri);
     for (int i = 0; i < L.numTriangles; ++i) {
         const TriRows tnxt = loadTri(sc + L.offTri + 3 * (i + 1));
-        const TriHit th = triangleTest(tcur, o, d, h.distance, live);
+        const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], sc[L.offPrimTri + 2 * i + 1], d,
+                                                         h.distance, live)
+                                   : triangleTest(tcur, o, d, h.distance, live);
         tcur = tnxt;
         if (th.hit) {
             h.distance = th.dist;
@@ -382,23 +446,37 @@ __device__ __forceinline__ uint32_t quantizeSample(float radiance) {
     return (v == v) ? (uint32_t)v : 0u;
 }
 
+// The per-pixel home record of the random stream: 8 words (v0..v4, d, 2 pad) = one 32-byte sector, so
+// parking or fetching a stream is two 16-byte accesses instead of six scattered 4-byte ones.
+__device__ __forceinline__ void loadHome(const uint32_t* __restrict__ home, uint32_t p, ptrng::State& s) {
+    const uint4 a = reinterpret_cast<const uint4*>(home)[2 * p];
+    const uint4 b = reinterpret_cast<const uint4*>(home)[2 * p + 1];
+    s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
+    s.v[4] = b.x; s.d = b.y;
+}
+__device__ __forceinline__ void storeHome(uint32_t* __restrict__ home, uint32_t p, const ptrng::State& s) {
+    reinterpret_cast<uint4*>(home)[2 * p] = uint4{s.v[0], s.v[1], s.v[2], s.v[3]};
+    reinterpret_cast<uint4*>(home)[2 * p + 1] = uint4{s.v[4], s.d, 0u, 0u};
+}
+
+struct U3 {  // one totalPixelColors entry, moved as a single 12-byte access
+    uint32_t x, y, z;
+};
+
 // A path ended: writeToPixelsKernel for this ray (CudaTracer.cu:63-104) + park the RNG stream.
 __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs& r) {
     const uint32_t p = r.pix;
-    uint32_t* acc = fb.accum + 3u * p;
-    const uint32_t tx = acc[0] + quantizeSample(r.L0.x);
-    const uint32_t ty = acc[1] + quantizeSample(r.L0.y);
-    const uint32_t tz = acc[2] + quantizeSample(r.L0.z);
-    acc[0] = tx;
-    acc[1] = ty;
-    acc[2] = tz;
+    U3* acc = reinterpret_cast<U3*>(fb.accum) + p;
+    U3 t = *acc;
+    t.x += quantizeSample(r.L0.x);
+    t.y += quantizeSample(r.L0.y);
+    t.z += quantizeSample(r.L0.z);
+    *acc = t;
     if (fb.pixels) {
-        ptss_uchar4 px;
-        px.x = (unsigned char)(tx * fb.inverseTicks + 0.5f);
-        px.y = (unsigned char)(ty * fb.inverseTicks + 0.5f);
-        px.z = (unsigned char)(tz * fb.inverseTicks + 0.5f);
-        px.w = 255;
-        fb.pixels[p] = px;
+        const uint32_t px = (uint32_t)(unsigned char)(t.x * fb.inverseTicks + 0.5f) |
+                            ((uint32_t)(unsigned char)(t.y * fb.inverseTicks + 0.5f) << 8) |
+                            ((uint32_t)(unsigned char)(t.z * fb.inverseTicks + 0.5f) << 16) | (255u << 24);
+        reinterpret_cast<uint32_t*>(fb.pixels)[p] = px;  // uchar4 {x, y, z, w = 255}
     }
     if (fb.fsum) {
         float* fs = fb.fsum + 3u * p;
@@ -406,14 +484,29 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
         fs[1] += r.L0.y;
         fs[2] += r.L0.z;
     }
-    const uint32_t cap = fb.homeStride;
-    fb.rngHome[0 * cap + p] = r.rng.v[0];
-    fb.rngHome[1 * cap + p] = r.rng.v[1];
-    fb.rngHome[2 * cap + p] = r.rng.v[2];
-    fb.rngHome[3 * cap + p] = r.rng.v[3];
-    fb.rngHome[4 * cap + p] = r.rng.v[4];
-    fb.rngHome[5 * cap + p] = r.rng.d;
+    storeHome(fb.rngHome, p, r.rng);
 }
+
+// ---- diagnostic build only (-DPTSS_STAMPS): per-phase wave-cycle accounting. The shipped kernel executes no stamp.
+#ifdef PTSS_STAMPS
+#define PTSS_STAMP_INIT() unsigned long long _st_prev = clock64(), _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PTSS_STAMP(k)                                             \
+    do {                                                          \
+        __builtin_amdgcn_s_waitcnt(0);                            \
+        const unsigned long long _t = clock64();                  \
+        _st_acc[k] += _t - _st_prev;                              \
+        _st_prev = _t;                                            \
+    } while (0)
+#define PTSS_STAMP_FLUSH()                                                        \
+    do {                                                                          \
+        if (lane == 0)                                                            \
+            for (int _k = 0; _k < 8; ++_k) atomicAdd(&fb.stamps[_k], _st_acc[_k]); \
+    } while (0)
+#else
+#define PTSS_STAMP_INIT() do {} while (0)
+#define PTSS_STAMP(k) do {} while (0)
+#define PTSS_STAMP_FLUSH() do {} while (0)
+#endif
 
 // ---- LDS work area behind the scene image -----------------------------------------------------
 // block: [0..kWaves) wave survivor totals, [8] block base in the output region
@@ -437,8 +530,7 @@ __global__ void rngInitKernel(uint32_t* __restrict__ rngHome, uint32_t capacity,
     const PixelCoord pc = locate(tile, i);
     ptrng::State s = ptrng::seeded(seed);
     ptrng::skip_subsequences(s, pc.globalIndex, jumpTable);
-    for (int k = 0; k < 5; ++k) rngHome[k * capacity + i] = s.v[k];
-    rngHome[5 * capacity + i] = s.d;
+    storeHome(rngHome, i, s);
 }
 
 __global__ void clearKernel(FrameBuffers fb) {
@@ -455,34 +547,21 @@ __global__ void clearKernel(FrameBuffers fb) {
     if (fb.pixels) fb.pixels[i] = ptss_uchar4{0, 0, 0, 0};
 }
 
-__global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int numBounces) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)kShards) {  // this frame's live-ray counters: bounce 0 = the shard's pixels, the rest 0
-        fb.counts[countIndex(0, (int)i)] = fb.shardCount0[i];
-        for (int b = 1; b <= numBounces; ++b) fb.counts[countIndex(b, (int)i)] = 0;
+// Origin-only parts of the primary-ray tests, one thread per primitive; rerun when the camera moves.
+__global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3 origin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L.numSpheres) {
+        const float4 sp = blob[L.offSphere + i];
+        const vec3 v = origin - xyz(sp);
+        blob[L.offPrimSphere + i] = float4{v.x, v.y, v.z, dot(v, v) - sp.w};
     }
-    if (i >= fb.numPixels) return;
-    const PixelCoord pc = locate(tile, i);
-    const uint32_t hs = fb.homeStride;
-    RayRegs r;
-    for (int k = 0; k < 5; ++k) r.rng.v[k] = fb.rngHome[k * hs + i];
-    r.rng.d = fb.rngHome[5 * hs + i];
-
-    const float jitteredX = pc.x + ptrng::uniform(r.rng);
-    const float jitteredY = pc.gy + ptrng::uniform(r.rng);
-    const vec3 start = v3(((jitteredX * eye.invW) - 0.5f) * eye.s,
-                          1 * ((jitteredY * eye.invH) - 0.5f) * eye.s * eye.aspect, 1.0f) *
-                       eye.camera.zNear;
-    r.o = eye.camera.position;
-    r.d = normalize(rotate(eye.camera.rotation, start));
-    r.L0 = v3(0, 0, 0);
-    r.T = v3(1, 1, 1);
-    r.pix = i;
-    r.active = true;
-    // tile t of the frame goes to shard t % kShards, as that shard's tile t / kShards
-    const uint32_t t = i / kBlock;
-    const uint32_t slot = (t % kShards) * fb.regionCap + (t / kShards) * kBlock + (i % kBlock);
-    storeRay(fb.pool[0], fb.capacity, slot, r);
+    if (i < L.numTriangles) {
+        const vec3 v0 = xyz(blob[L.offTri + 3 * i]), e1 = xyz(blob[L.offTri + 3 * i + 1]), e2 = xyz(blob[L.offTri + 3 * i + 2]);
+        const vec3 s = origin - v0;
+        const vec3 r = cross(s, e1);
+        blob[L.offPrimTri + 2 * i] = float4{s.x, s.y, s.z, dot(e2, r)};
+        blob[L.offPrimTri + 2 * i + 1] = float4{r.x, r.y, r.z, 0.0f};
+    }
 }
 
 // kSceneInLds = true : the scene blob is staged into LDS once per workgroup and read by broadcast
@@ -506,15 +585,21 @@ __global__ void eyeRaysKernel(FrameBuffers fb, TileMap tile, EyeParams eye, int 
 // (distance2 in (0, inf); light powers and diffuse colours are checked finite at ptss_create,
 // SceneLayout::neeSkipSafe), and radiance + (+-0) == radiance, so visibility cannot change the
 // result and the segment is not traced. Every other case runs the literal path.
-template <bool kLast, bool kSceneInLds>
+//
+// kFirst: bounce 0 makes its own rays — computeEyeRaysKernel (CudaTracer.cu:51-61, 321-343) is fused in: the
+// lane fetches its pixel's random stream from the home record, draws the two jitter samples, builds the
+// eye ray in registers (no ray pool read) and intersects with the camera-origin precomputes.
+template <bool kLast, bool kSceneInLds, bool kFirst>
 __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
-                                                                      SceneLayout L, int bounce) {
+                                                                      SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
     extern __shared__ float4 lds[];
     const uint32_t shard = blockIdx.x % kShards;
-    uint32_t liveTotal = 0;
-    for (int s = 0; s < kShards; ++s) liveTotal += fb.counts[countIndex(bounce, s)];
-    if (liveTotal <= fb.minLive) return;  // loop guard, CudaTracer.cu:622 (device-side; same for every workgroup)
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays
+    if (n <= fb.minLive) {  // loop guard, CudaTracer.cu:622, on the FRAME's live count (device-side; every
+        uint32_t liveTotal = 0;  // workgroup reaches the same verdict). Only a nearly empty shard has to add up.
+        for (int s = 0; s < kShards; ++s) liveTotal += fb.counts[countIndex(bounce, s)];
+        if (liveTotal <= fb.minLive) return;
+    }
 
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -544,18 +629,41 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
         const bool valid = i < n;
 
         // ---- 1. closest hit + surfel (pathTraceKernel :121-163) -----------------------------------
+        PTSS_STAMP_INIT();
         RayRegs ray;
         ray.o = ray.d = ray.L0 = ray.T = v3(0, 0, 0);
         ray.pix = 0;
         ray.active = false;
-        if (valid) loadRay(in, cap, i, ray);
+        if constexpr (kFirst) {
+            if (valid) {
+                // tile (base/kBlock) of shard `shard` is frame tile t = (base/kBlock)*kShards + shard (eye order)
+                const uint32_t pixel = ((base / kBlock) * kShards + shard) * kBlock + threadIdx.x;
+                const PixelCoord pc = locate(tile, pixel);
+                loadHome(fb.rngHome, pixel, ray.rng);
+                const float jitteredX = pc.x + ptrng::uniform(ray.rng);
+                const float jitteredY = pc.gy + ptrng::uniform(ray.rng);
+                const vec3 start = v3(((jitteredX * eye.invW) - 0.5f) * eye.s,
+                                      1 * ((jitteredY * eye.invH) - 0.5f) * eye.s * eye.aspect, 1.0f) *
+                                   eye.camera.zNear;
+                ray.o = eye.camera.position;
+                ray.d = normalize(rotate(eye.camera.rotation, start));
+                ray.L0 = v3(0, 0, 0);
+                ray.T = v3(1, 1, 1);
+                ray.pix = pixel;
+                ray.active = true;
+            }
+        } else {
+            if (valid) loadRay(in, cap, i, ray);
+        }
+        PTSS_STAMP(0);  // ray load / eye-ray generation
 #if PTSS_ABLATE & 2
         Hit h;
         h.kind = 2; h.idx = (int)(ray.pix % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit(sc, L, ray.o, ray.d, valid);
+        const Hit h = closestHit<kFirst>(sc, L, ray.o, ray.d, valid);
 #endif
+        PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
         float cosI = 0;
@@ -638,6 +746,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 queued += (uint32_t)__popcll(m);
             }
             waveLdsFence();
+            PTSS_STAMP(2);  // surfel + light sampling + enqueue
             for (uint32_t e0 = 0; e0 < queued; e0 += 64) {  // dense passes over the wave's queue
                 const uint32_t e = e0 + lane;
                 const bool have = e < queued;
@@ -651,6 +760,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 }
             }
             waveLdsFence();
+            PTSS_STAMP(3);  // dense shadow passes
 #pragma unroll
             for (int k = 0; k < kNeeLights; ++k) {
                 const int li = l0 + k;
@@ -684,13 +794,38 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 ray.active = false;
             }
             alive = ray.active && !kLast;
-            // ---- 4. writeToPixelsKernel for a finished path -------------------------------------
-            if (!alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
         }
+        PTSS_STAMP(4);  // lambert terms + scatter + radiance update
 
-        // ---- 5. stream compaction of the survivors (replaces thrust::partition, :629): 64-bit
-        // ballot + lane rank inside the wave, the wave totals combined through LDS, ONE atomic per
-        // workgroup on the shard's device-resident counter ---------------------------------------
+        // ---- 4+5. stream compaction of the survivors (replaces thrust::partition, :629) and
+        // writeToPixelsKernel for the paths that ended. PTSS_WAVE_COMPACT: each wave compacts on its
+        // own — 64-bit ballot, popcount lane rank, ONE returning atomic per wave on the shard's counter
+        // (16 counters share the load) — no barrier; the atomic is issued first so that its round trip
+        // hides behind the tone-mapping of the finished lanes. Otherwise: wave totals combined through
+        // LDS and one atomic per workgroup.
+#if PTSS_WAVE_COMPACT
+        uint32_t slot = 0;
+        if constexpr (!kLast) {
+            const unsigned long long live = __ballot(alive);
+            if (live) {
+                const int leader = __ffsll((long long)live) - 1;
+                uint32_t base0 = 0;
+                if ((int)lane == leader)
+                    base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], (uint32_t)__popcll(live));
+                slot = base0;  // consumed after the finish work below
+                if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+                slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
+                if (alive) storeRay(out, cap, slot, ray);
+            } else if (valid && !(PTSS_ABLATE & 8)) {
+                finishPath(fb, ray);
+            }
+        } else {
+            if (valid && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+        }
+        PTSS_STAMP(5);
+#else
+        if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+        PTSS_STAMP(5);  // finish (tone map, accumulate, park RNG)
         if constexpr (!kLast) {
             const unsigned long long live = __ballot(alive);
             const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
@@ -707,6 +842,9 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
             if (alive) storeRay(out, cap, slot, ray);
             __syncthreads();  // scratch is rewritten by the next tile
         }
+#endif
+        PTSS_STAMP(6);  // compaction (barriers, atomic, survivor stores)
+        PTSS_STAMP_FLUSH();
     }
 }
 
@@ -730,15 +868,37 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
         sum += totals[b];
     }
     if (threadIdx.x == 0) *fb.totalRayBounces += sum;
-    if (totals[stop] == 0) return;  // the last bounce ran: nothing left alive
     const uint32_t i = threadIdx.x;
-    for (int s = 0; s < kShards; ++s) {
-        const uint32_t n = fb.counts[countIndex(stop, s)];
-        if (i < n) {
+    if (stop == 0) {
+        // Not even bounce 0 ran (<= 128 pixels in the frame). Eye rays are made inside bounce 0, so there are
+        // none in the pool: do what computeEyeRaysKernel + writeToPixelsKernel would have done to each pixel —
+        // two jitter draws, then a sample of radiance 0.
+        if (i < fb.numPixels) {
             RayRegs ray;
-            loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);
+            loadHome(fb.rngHome, i, ray.rng);
+            (void)ptrng::uniform(ray.rng);
+            (void)ptrng::uniform(ray.rng);
+            ray.L0 = v3(0, 0, 0);
+            ray.pix = i;
             finishPath(fb, ray);
         }
+    } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
+        for (int s = 0; s < kShards; ++s) {
+            const uint32_t n = fb.counts[countIndex(stop, s)];
+            if (i < n) {
+                RayRegs ray;
+                loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);
+                finishPath(fb, ray);
+            }
+        }
+    }
+    // keep this frame's counters for the host (live counts, grid hints), and re-arm them for the next frame:
+    // bounce 0 = the shard's pixels, every later bounce 0
+    __syncthreads();
+    for (int k = threadIdx.x; k < (numBounces + 1) * kShards; k += blockDim.x) {
+        const int b = k / kShards, s = k % kShards;
+        fb.lastCounts[countIndex(b, s)] = fb.counts[countIndex(b, s)];
+        fb.counts[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
     }
 }
 
@@ -757,16 +917,19 @@ hipError_t launchClear(hipStream_t st, const FrameBuffers& fb) {
     return hipGetLastError();
 }
 
-hipError_t launchEyeRays(hipStream_t st, const FrameBuffers& fb, TileMap tile, EyeParams eye, int numBounces) {
-    hipLaunchKernelGGL(eyeRaysKernel, dim3(blocksFor(fb.numPixels, 256)), dim3(256), 0, st, fb, tile, eye, numBounces);
+hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayout& layout, ptss_vec3 origin) {
+    const int n = layout.numSpheres > layout.numTriangles ? layout.numSpheres : layout.numTriangles;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(primaryPrepKernel, dim3(blocksFor((uint32_t)n, 64)), dim3(64), 0, st, sceneBlob, layout, origin);
     return hipGetLastError();
 }
 
-template <bool kLast, bool kLds>
+template <bool kLast, bool kLds, bool kFirst>
 static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout,
-                                int bounce, int gridBlocks) {
+                                int bounce, int gridBlocks, const TileMap& tile, const EyeParams& eye) {
     const size_t lds = bounceLdsBytes(layout, kLds);
-    hipLaunchKernelGGL((bounceKernel<kLast, kLds>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce);
+    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
+                       tile, eye);
     return hipGetLastError();
 }
 
@@ -775,12 +938,16 @@ size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
 }
 
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, bool sceneInLds, int gridBlocks) {
-    if (sceneInLds)
-        return isLast ? launchBounceT<true, true>(st, fb, sceneBlob, layout, bounce, gridBlocks)
-                      : launchBounceT<false, true>(st, fb, sceneBlob, layout, bounce, gridBlocks);
-    return isLast ? launchBounceT<true, false>(st, fb, sceneBlob, layout, bounce, gridBlocks)
-                  : launchBounceT<false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks);
+                        bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye) {
+    const bool isFirst = bounce == 0;
+#define PTSS_GO(a, b, c) return launchBounceT<a, b, c>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye)
+    if (sceneInLds) {
+        if (isFirst) { if (isLast) PTSS_GO(true, true, true); else PTSS_GO(false, true, true); }
+        if (isLast) PTSS_GO(true, true, false); else PTSS_GO(false, true, false);
+    }
+    if (isFirst) { if (isLast) PTSS_GO(true, false, true); else PTSS_GO(false, false, true); }
+    if (isLast) PTSS_GO(true, false, false); else PTSS_GO(false, false, false);
+#undef PTSS_GO
 }
 
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
@@ -791,8 +958,8 @@ hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
 int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds) {
     const size_t lds = bounceLdsBytes(layout, sceneInLds);
     int a = 0;
-    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true>, kBlock, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false>, kBlock, lds);
+    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false>, kBlock, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false>, kBlock, lds);
     return e == hipSuccess ? a : 0;
 }
 

@@ -94,6 +94,10 @@ int ptss_total_ray_bounces(ptss_context* ctx, unsigned long long* out);
 /* HIP-event time of the bounce kernel since the last call (needs cfg.timeKernels): total ms, launches. */
 int ptss_bounce_kernel_time(ptss_context* ctx, double* total_ms, unsigned long long* launches);
 
+/* Diagnostic builds only (-DPTSS_STAMPS, tools/build_variants.py "stamps"): wave-cycles spent per kernel
+ * phase, summed over all waves since creation; all zero in the shipped library. */
+int ptss_debug_phase_cycles(ptss_context* ctx, unsigned long long* out8);
+
 const char* ptss_error_string(int code);
 const char* ptss_last_error_detail(void);
 int ptss_version(void);

@@ -16,6 +16,12 @@ VARIANTS = {
     "b512": ["PTSS_BLOCK=512"],
     "s8": ["PTSS_SHARDS=8"],
     "s32": ["PTSS_SHARDS=32"],
+    "stamps": ["PTSS_STAMPS=1"],
+    "blockc": ["PTSS_WAVE_COMPACT=0"],
+    "wc_s32": ["PTSS_SHARDS=32"],
+    "wc_s64": ["PTSS_SHARDS=64"],
+    "wc_b128": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
+    "wc_b64": ["PTSS_BLOCK=64", "PTSS_SHARDS=64"],
     # ablations (results are WRONG by construction; timing only)
     "a1": ["PTSS_ABLATE=1"],
     "a2": ["PTSS_ABLATE=2"],
