@@ -88,14 +88,25 @@ def build_main(force=False):
     return out
 
 
+def build_mathcheck(force=False):
+    """ptss_mathcheck: exhaustive float32 check of the device fast paths of ptm::rcp / ptm::sqrt (tests/test_gpu_math.py)."""
+    out = os.path.join(LIBDIR, "ptss_mathcheck")
+    src = os.path.join(ROOT, "tests", "csrc", "math_exhaustive.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if force or _newer(out, [src] + _headers()):
+        _run([hipcc] + [f for f in HIP_FLAGS if f != "-fPIC"] + ["-I", INC, "-I", CSRC, src, "-o", out])
+    return out
+
+
 def build_all(force=False):
-    return [build_host(force), build_oracle(force), build_device(force), build_main(force)]
+    return [build_host(force), build_oracle(force), build_device(force), build_main(force), build_mathcheck(force)]
 
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
     what = [a for a in sys.argv[1:] if not a.startswith("-")]
-    table = {"host": build_host, "oracle": build_oracle, "device": build_device, "main": build_main}
+    table = {"host": build_host, "oracle": build_oracle, "device": build_device, "main": build_main,
+             "mathcheck": build_mathcheck}
     if not what:
         build_all(force)
     for w in what:

@@ -140,7 +140,7 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     const vec3 v0 = xyz(tr.a), e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
-    const float inverseDet = 1 / det;
+    const float inverseDet = ptm::rcp(det);  // 1 / det, Primitives.h:44
     const vec3 s = o - v0;
     const vec3 r = cross(s, e1);
     const float dist = dot(e2, r) * inverseDet;
@@ -198,7 +198,7 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
     const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
-    const float inverseDet = 1 / det;
+    const float inverseDet = ptm::rcp(det);  // 1 / det, Primitives.h:44
     const float dist = ps.w * inverseDet;
     const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
     TriHit h;
@@ -258,13 +258,11 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
             }
         }
     }
-    TriRows tcur = loadTri(sc + L.offTri);
     for (int i = 0; i < L.numTriangles; ++i) {
-        const TriRows tnxt = loadTri(sc + L.offTri + 3 * (i + 1));
+        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
         const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], sc[L.offPrimTri + 2 * i + 1], d,
                                                          h.distance, live)
                                    : triangleTest(tcur, o, d, h.distance, live);
-        tcur = tnxt;
         if (th.hit) {
             h.distance = th.dist;
             h.kind = 2;
@@ -299,12 +297,10 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
             }
         }
     }
-    TriRows tcur = loadTri(sc + L.offTri);
     for (int i = 0; i < L.numTriangles; ++i) {
         if (!__any(live && !occluded)) break;
-        const TriRows tnxt = loadTri(sc + L.offTri + 3 * (i + 1));
+        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
         const TriHit th = triangleTest(tcur, lo, w_i, distance, live && !occluded);
-        tcur = tnxt;
         occluded = occluded || th.hit;
     }
     return occluded;
@@ -414,7 +410,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
             if (mMisc.x != ptm::inf()) {  // randomDirectionPhong :547-559
                 const float theta = ptrng::uniform(ray.rng) * 2 * ptm::kPi;
                 const float s = ptrng::uniform(ray.rng);
-                ray.d = lobeSample(ray.d, theta, ptm::pow(s, 1 / (mMisc.x + 1)));
+                ray.d = lobeSample(ray.d, theta, ptm::pow(s, ptm::rcp(mMisc.x + 1)));
             }
             return xyz(mSpecular);
         }
@@ -710,7 +706,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                         const float u1 = ptrng::uniform(ray.rng);
                         const float u2 = ptrng::uniform(ray.rng);
                         const float u3 = ptrng::uniform(ray.rng);
-                        const float inverseTotal = 1 / (u1 + u2 + u3);
+                        const float inverseTotal = ptm::rcp(u1 + u2 + u3);  // 1 / (u1+u2+u3), :403
                         const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
                         const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
                         const vec3 a = xyz(sc[L.offTri + 3 * tri]);

@@ -11,6 +11,7 @@ spec.loader.exec_module(b)
 
 VARIANTS = {
     "w1": ["PTSS_MINWAVES=1"],
+    "w4": ["PTSS_MINWAVES=4"],
     "w6": ["PTSS_MINWAVES=6"],
     "b128": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
     "b512": ["PTSS_BLOCK=512"],
