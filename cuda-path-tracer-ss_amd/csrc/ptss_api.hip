@@ -59,6 +59,7 @@ struct ptss_context {
     float* dFsum = nullptr;
     uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
     uint32_t poolStride = 0, regionCap = 0;  // ray pools: kShards regions of regionCap slots
+    uint32_t samples = 1;                    // cfg.samplesPerPass (sample lanes per pixel)
     uint32_t* dShardCount0 = nullptr;
     uint32_t* dLastCounts = nullptr;   // counts of the frame before (flushKernel's copy)
     bool cameraDirty = true;           // primary-ray precomputes must be refreshed
@@ -189,11 +190,14 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.capacity = c->poolStride;
     fb.regionCap = c->regionCap;
     fb.numPixels = c->numPixels;
+    fb.plane = c->capacity;
+    fb.samples = c->samples;
+    fb.firstTiles = c->samples * (c->capacity / ptss::kBlock);
     // The reference stops bouncing once <= 128 rays are live IN THE WHOLE FRAME (CudaTracer.cu:622). A
     // shard cannot know the frame-wide count without a collective per bounce, so a sharded context
     // never stops early; the two agree whenever the frame-wide count stays above 128.
     fb.minLive = c->tile.world > 1 ? 0u : ptss::kMinLiveRays;
-    fb.inverseTicks = 1.f / (sample + 1);  // CudaTracer.cu:94
+    fb.inverseTicks = 1.f / (float)((int)c->samples * (sample + 1));  // CudaTracer.cu:94 (S = 1: 1.f / (ticks + 1))
     fb.defaultColor[0] = c->defaultColor[0];
     fb.defaultColor[1] = c->defaultColor[1];
     fb.defaultColor[2] = c->defaultColor[2];
@@ -254,6 +258,7 @@ int ptss_default_config(ptss_render_config* cfg) {
     cfg->syncEachFrame = 1;
     cfg->floatAccumulator = 0;
     cfg->timeKernels = 0;
+    cfg->samplesPerPass = 1;
     return PTSS_OK;
 }
 
@@ -265,6 +270,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         return fail(PTSS_EINVAL, "maxIterations must be in [1, 64]");
     if (cfg->tileWorld <= 0 || cfg->tileRank < 0 || cfg->tileRank >= cfg->tileWorld || cfg->bandRows <= 0)
         return fail(PTSS_EINVAL, "bad tile spec");
+    const int spp = cfg->samplesPerPass == 0 ? 1 : cfg->samplesPerPass;
+    if (spp < 1 || spp > 16) return fail(PTSS_EINVAL, "samplesPerPass must be in [1, 16]");
+    if ((long long)cfg->width * cfg->height >= (1ll << 28)) return fail(PTSS_EINVAL, "frame too large (>= 2^28 pixels)");
     int rc = validateScene(*scene);
     if (rc != PTSS_OK) return rc;
 
@@ -281,6 +289,7 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     if (!c) return fail(PTSS_ENOMEM, "context");
     c->cfg = *cfg;
     c->maxIterations = cfg->maxIterations;
+    c->samples = (uint32_t)spp;
     c->defaultColor[0] = scene->defaultColor.x;
     c->defaultColor[1] = scene->defaultColor.y;
     c->defaultColor[2] = scene->defaultColor.z;
@@ -296,17 +305,21 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         if ((y / cfg->bandRows) % cfg->tileWorld == cfg->tileRank) ++localRows;
     c->tile = ptss::TileMap{cfg->width, cfg->height, localRows, cfg->tileRank, cfg->tileWorld, cfg->bandRows};
     c->numPixels = (uint32_t)cfg->width * (uint32_t)localRows;
-    c->capacity = ((c->numPixels + 255u) / 256u) * 256u;
-    if (c->capacity == 0) c->capacity = 256;
+    const uint32_t gran = ptss::kBlock > 256 ? (uint32_t)ptss::kBlock : 256u;  // pixel planes are whole tiles
+    c->capacity = ((c->numPixels + gran - 1) / gran) * gran;
+    if (c->capacity == 0) c->capacity = gran;
     uint32_t shardCount0[ptss::kShards] = {0};
     {
-        const uint32_t tiles = (c->numPixels + ptss::kBlock - 1) / ptss::kBlock;
+        // bounce 0 walks S sample planes of `capacity` pixels (capacity = numPixels rounded up to a tile)
+        const uint32_t tilesPerPlane = c->capacity / ptss::kBlock;
+        const uint32_t tiles = tilesPerPlane * c->samples;
         const uint32_t tilesPerShard = (tiles + ptss::kShards - 1) / ptss::kShards;
         c->regionCap = (tilesPerShard ? tilesPerShard : 1) * ptss::kBlock;
         c->poolStride = c->regionCap * ptss::kShards;
         for (uint32_t t = 0; t < tiles; ++t) {
-            const uint32_t first = t * ptss::kBlock;
-            const uint32_t cnt = c->numPixels - first < (uint32_t)ptss::kBlock ? c->numPixels - first : (uint32_t)ptss::kBlock;
+            const uint32_t first = (t % tilesPerPlane) * ptss::kBlock;  // first pixel of the tile inside its plane
+            uint32_t cnt = 0;
+            if (first < c->numPixels) cnt = c->numPixels - first < (uint32_t)ptss::kBlock ? c->numPixels - first : (uint32_t)ptss::kBlock;
             shardCount0[t % ptss::kShards] += cnt;
         }
     }
@@ -334,7 +347,7 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     const size_t poolBytes = (size_t)ptss::kRayPlanes * c->poolStride * sizeof(float);
     CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
     CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
-    CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kHomeWords * c->capacity * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kHomeWords * c->capacity * c->samples * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&c->dCounts, ptss::kCountWords * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->dCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&c->dLastCounts, ptss::kCountWords * sizeof(uint32_t)));
@@ -349,8 +362,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     CREATE_TRY(hipMemset(c->dAccumOwned, 0, (size_t)3 * c->capacity * sizeof(uint32_t)));
     c->dAccum = c->dAccumOwned;
     if (cfg->floatAccumulator) {
-        CREATE_TRY(hipMalloc(&c->dFsum, (size_t)3 * c->capacity * sizeof(float)));
-        CREATE_TRY(hipMemset(c->dFsum, 0, (size_t)3 * c->capacity * sizeof(float)));
+        CREATE_TRY(hipMalloc(&c->dFsum, (size_t)3 * c->capacity * c->samples * sizeof(float)));
+        CREATE_TRY(hipMemset(c->dFsum, 0, (size_t)3 * c->capacity * c->samples * sizeof(float)));
     }
     CREATE_TRY(hipEventCreate(&c->evStart));
     CREATE_TRY(hipEventCreate(&c->evStop));
@@ -364,7 +377,7 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         hipError_t e1 = hipMemcpy(dTable, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         hipError_t e2 = e1;
         if (e1 == hipSuccess && c->numPixels > 0)
-            e2 = ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->tile, cfg->seed, dTable);
+            e2 = ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->samples, c->tile, cfg->seed, dTable);
         hipError_t e3 = e2 == hipSuccess ? hipDeviceSynchronize() : e2;
         (void)hipFree(dTable);
         CREATE_TRY(e3);
@@ -504,6 +517,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         }
     }
     HIP_TRY(ptss::launchFlush(st, fb, numIterations));  // :637
+    if (c->samples > 1 && pixels) HIP_TRY(ptss::launchDisplay(st, fb));  // display value once all S samples are in
 
     // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
     if (!c->haveHint || (c->frameIndex & 7u) == 0) {
@@ -637,7 +651,16 @@ int ptss_read_float_accumulator(ptss_context* c, float* host, size_t count) {
     if (!c->dFsum) return fail(PTSS_EINVAL, "context was created without floatAccumulator");
     if (count != (size_t)3 * c->numPixels) return fail(PTSS_ERANGE, "count must be 3 * local pixels");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(host, c->dFsum, count * sizeof(float), hipMemcpyDeviceToHost));
+    if (c->samples == 1) {
+        HIP_TRY(hipMemcpy(host, c->dFsum, count * sizeof(float), hipMemcpyDeviceToHost));
+    } else {  // per-stream sums, added in lane order 0..S-1 (a fixed order: reproducible, and what the oracle does)
+        std::vector<float> lane(count);
+        for (size_t k = 0; k < count; ++k) host[k] = 0.0f;
+        for (uint32_t l = 0; l < c->samples; ++l) {
+            HIP_TRY(hipMemcpy(lane.data(), c->dFsum + (size_t)3 * l * c->capacity, count * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < count; ++k) host[k] = host[k] + lane[k];
+        }
+    }
     return PTSS_OK;
 }
 
@@ -649,11 +672,14 @@ int ptss_read_pixels(ptss_context* c, const ptss_uchar4* dev, ptss_uchar4* host,
     return PTSS_OK;
 }
 
-int ptss_read_rng_state(ptss_context* c, size_t local_pixel, uint32_t* out6) {
+int ptss_read_rng_state(ptss_context* c, size_t local_pixel, uint32_t* out6) { return ptss_read_rng_state_lane(c, local_pixel, 0, out6); }
+
+int ptss_read_rng_state_lane(ptss_context* c, size_t local_pixel, unsigned int lane, uint32_t* out6) {
     if (!c || !out6) return fail(PTSS_EINVAL, "null argument");
-    if (local_pixel >= c->numPixels) return fail(PTSS_ERANGE, "pixel out of range");
+    if (local_pixel >= c->numPixels || lane >= c->samples) return fail(PTSS_ERANGE, "pixel or lane out of range");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out6, c->dRngHome + (size_t)ptss::kHomeWords * local_pixel, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out6, c->dRngHome + (size_t)ptss::kHomeWords * ((size_t)lane * c->capacity + local_pixel), 6 * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
     return PTSS_OK;
 }
 
@@ -665,7 +691,7 @@ int ptss_last_pass_ms(ptss_context* c, float* out) {
 
 int ptss_samples_since_reset(const ptss_context* c, int* out) {
     if (!c || !out) return fail(PTSS_EINVAL, "null argument");
-    *out = c->resetTicksThisFrame ? 0 : (c->lastTicks - c->lastResetTick + 1);
+    *out = c->resetTicksThisFrame ? 0 : (c->lastTicks - c->lastResetTick + 1) * (int)c->samples;
     return PTSS_OK;
 }
 

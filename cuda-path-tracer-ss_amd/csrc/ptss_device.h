@@ -100,6 +100,9 @@ struct FrameBuffers {
     uint32_t capacity;       // pool plane stride = kShards * regionCap
     uint32_t regionCap;      // slots per shard region
     uint32_t numPixels;      // local pixels
+    uint32_t plane;          // numPixels rounded up to kBlock: stride of the per-pixel planes (one plane per sample lane)
+    uint32_t samples;        // S = cfg.samplesPerPass: independent random streams per pixel traced per pass
+    uint32_t firstTiles;     // tiles of bounce 0 = S * plane / kBlock
     uint32_t minLive;        // a bounce runs while more than this many rays are live: 128 (CudaTracer.cu:622),
                              // 0 in a sharded context (the guard is a whole-frame quantity; DESIGN.md "Sharding")
     float inverseTicks;      // 1.f / (ticks - lastResetTick + 1)
@@ -107,8 +110,9 @@ struct FrameBuffers {
 };
 
 // ---- launchers (ptss_kernels.hip) --------------------------------------------------------------
-hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t capacity, TileMap tile, uint64_t seed,
+hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t plane, uint32_t samples, TileMap tile, uint64_t seed,
                          const uint32_t* jumpTable);
+hipError_t launchDisplay(hipStream_t st, const FrameBuffers& fb);
 hipError_t launchClear(hipStream_t st, const FrameBuffers& fb);
 hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayout& layout, ptss_vec3 origin);
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,

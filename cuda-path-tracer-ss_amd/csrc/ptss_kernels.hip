@@ -50,6 +50,12 @@ __device__ __forceinline__ PixelCoord locate(const TileMap& t, uint32_t local) {
     return p;
 }
 
+// Ray::pixelOffset as carried by a ray: local pixel in the low 28 bits, sample lane (0..S-1, S <= 16) above.
+// S = cfg.samplesPerPass independent random streams per pixel are traced per pass (1 = the reference).
+constexpr uint32_t kPixMask = 0x0fffffffu;
+__device__ __forceinline__ uint32_t pixOf(uint32_t packed) { return packed & kPixMask; }
+__device__ __forceinline__ uint32_t laneOf(uint32_t packed) { return packed >> 28; }
+
 struct RayRegs {
     vec3 o, d, L0, T;
     uint32_t pix;
@@ -460,27 +466,38 @@ struct U3 {  // one totalPixelColors entry, moved as a single 12-byte access
 };
 
 // A path ended: writeToPixelsKernel for this ray (CudaTracer.cu:63-104) + park the RNG stream.
+// With S > 1 sample lanes several lanes of a launch may end paths of the SAME pixel: the integer sums then
+// go through atomics (order-free, still exact), the display value is written by displayKernel once the
+// pass is complete, and the float sum is kept per stream (one writer each; summed in lane order on read).
 __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs& r) {
-    const uint32_t p = r.pix;
-    U3* acc = reinterpret_cast<U3*>(fb.accum) + p;
-    U3 t = *acc;
-    t.x += quantizeSample(r.L0.x);
-    t.y += quantizeSample(r.L0.y);
-    t.z += quantizeSample(r.L0.z);
-    *acc = t;
-    if (fb.pixels) {
-        const uint32_t px = (uint32_t)(unsigned char)(t.x * fb.inverseTicks + 0.5f) |
-                            ((uint32_t)(unsigned char)(t.y * fb.inverseTicks + 0.5f) << 8) |
-                            ((uint32_t)(unsigned char)(t.z * fb.inverseTicks + 0.5f) << 16) | (255u << 24);
-        reinterpret_cast<uint32_t*>(fb.pixels)[p] = px;  // uchar4 {x, y, z, w = 255}
+    const uint32_t p = pixOf(r.pix), lane = laneOf(r.pix);
+    const uint32_t stream = lane * fb.plane + p;
+    const uint32_t qx = quantizeSample(r.L0.x), qy = quantizeSample(r.L0.y), qz = quantizeSample(r.L0.z);
+    if (fb.samples == 1) {
+        U3* acc = reinterpret_cast<U3*>(fb.accum) + p;
+        U3 t = *acc;
+        t.x += qx;
+        t.y += qy;
+        t.z += qz;
+        *acc = t;
+        if (fb.pixels) {
+            const uint32_t px = (uint32_t)(unsigned char)(t.x * fb.inverseTicks + 0.5f) |
+                                ((uint32_t)(unsigned char)(t.y * fb.inverseTicks + 0.5f) << 8) |
+                                ((uint32_t)(unsigned char)(t.z * fb.inverseTicks + 0.5f) << 16) | (255u << 24);
+            reinterpret_cast<uint32_t*>(fb.pixels)[p] = px;  // uchar4 {x, y, z, w = 255}
+        }
+    } else {
+        atomicAdd(fb.accum + 3u * p + 0, qx);
+        atomicAdd(fb.accum + 3u * p + 1, qy);
+        atomicAdd(fb.accum + 3u * p + 2, qz);
     }
     if (fb.fsum) {
-        float* fs = fb.fsum + 3u * p;
+        float* fs = fb.fsum + 3u * stream;
         fs[0] += r.L0.x;
         fs[1] += r.L0.y;
         fs[2] += r.L0.z;
     }
-    storeHome(fb.rngHome, p, r.rng);
+    storeHome(fb.rngHome, stream, r.rng);
 }
 
 // ---- diagnostic build only (-DPTSS_STAMPS): per-phase wave-cycle accounting. The shipped kernel executes no stamp.
@@ -518,14 +535,17 @@ constexpr int kBlockLdsVec4 = kBlockScratchVec4 + (kWaves * kWaveLdsWords + 3) /
 }  // namespace
 
 // =================================================================================================
-__global__ void rngInitKernel(uint32_t* __restrict__ rngHome, uint32_t capacity, TileMap tile, uint64_t seed,
+// curand_init(seed, sequence, 0, ...) per stream: sequence = globalPixel * S + lane (S = 1: the pixel index,
+// as the reference's `offset`, CudaTracer.cu:26-28)
+__global__ void rngInitKernel(uint32_t* __restrict__ rngHome, uint32_t plane, uint32_t samples, TileMap tile, uint64_t seed,
                               const uint32_t* __restrict__ jumpTable) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)tile.width * (uint32_t)tile.localRows;
-    if (i >= n) return;
-    const PixelCoord pc = locate(tile, i);
+    const uint32_t lane = i / plane, p = i - lane * plane;
+    if (lane >= samples || p >= n) return;
+    const PixelCoord pc = locate(tile, p);
     ptrng::State s = ptrng::seeded(seed);
-    ptrng::skip_subsequences(s, pc.globalIndex, jumpTable);
+    ptrng::skip_subsequences(s, pc.globalIndex * samples + lane, jumpTable);
     storeHome(rngHome, i, s);
 }
 
@@ -535,12 +555,25 @@ __global__ void clearKernel(FrameBuffers fb) {
     fb.accum[3 * i] = 0;
     fb.accum[3 * i + 1] = 0;
     fb.accum[3 * i + 2] = 0;
-    if (fb.fsum) {
-        fb.fsum[3 * i] = 0;
-        fb.fsum[3 * i + 1] = 0;
-        fb.fsum[3 * i + 2] = 0;
-    }
+    if (fb.fsum)
+        for (uint32_t l = 0; l < fb.samples; ++l) {
+            float* fs = fb.fsum + 3u * (l * fb.plane + i);
+            fs[0] = 0;
+            fs[1] = 0;
+            fs[2] = 0;
+        }
     if (fb.pixels) fb.pixels[i] = ptss_uchar4{0, 0, 0, 0};
+}
+
+// S > 1 only: the display value of writeToPixelsKernel (CudaTracer.cu:94-98), once the pass has added all its samples
+__global__ void displayKernel(FrameBuffers fb) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.numPixels) return;
+    const U3 t = reinterpret_cast<const U3*>(fb.accum)[p];
+    const uint32_t px = (uint32_t)(unsigned char)(t.x * fb.inverseTicks + 0.5f) |
+                        ((uint32_t)(unsigned char)(t.y * fb.inverseTicks + 0.5f) << 8) |
+                        ((uint32_t)(unsigned char)(t.z * fb.inverseTicks + 0.5f) << 16) | (255u << 24);
+    reinterpret_cast<uint32_t*>(fb.pixels)[p] = px;
 }
 
 // Origin-only parts of the primary-ray tests, one thread per primitive; rerun when the camera moves.
@@ -620,9 +653,19 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
     const int numLights = L.numPointLights + L.numAreaLights;
 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
-    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < n; base += (gridDim.x / kShards) * kBlock) {
+    // bounce 0 walks the FRAME's tiles (S sample planes of fb.plane pixels; tile t belongs to shard t % kShards),
+    // every later bounce walks the shard's compacted region
+    const uint32_t span = kFirst ? ((fb.firstTiles + kShards - 1 - shard) / kShards) * kBlock : n;
+    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock) {
         const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n;
+        uint32_t firstPixel = 0, firstLane = 0;
+        bool valid = i < n;
+        if constexpr (kFirst) {
+            const uint32_t start = ((base / kBlock) * kShards + shard) * kBlock;  // frame tile -> first population index
+            firstLane = start / fb.plane;                                         // wave-uniform
+            firstPixel = start - firstLane * fb.plane + threadIdx.x;
+            valid = firstPixel < fb.numPixels;
+        }
 
         // ---- 1. closest hit + surfel (pathTraceKernel :121-163) -----------------------------------
         PTSS_STAMP_INIT();
@@ -632,10 +675,9 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
         ray.active = false;
         if constexpr (kFirst) {
             if (valid) {
-                // tile (base/kBlock) of shard `shard` is frame tile t = (base/kBlock)*kShards + shard (eye order)
-                const uint32_t pixel = ((base / kBlock) * kShards + shard) * kBlock + threadIdx.x;
+                const uint32_t pixel = firstPixel;
                 const PixelCoord pc = locate(tile, pixel);
-                loadHome(fb.rngHome, pixel, ray.rng);
+                loadHome(fb.rngHome, firstLane * fb.plane + pixel, ray.rng);
                 const float jitteredX = pc.x + ptrng::uniform(ray.rng);
                 const float jitteredY = pc.gy + ptrng::uniform(ray.rng);
                 const vec3 start = v3(((jitteredX * eye.invW) - 0.5f) * eye.s,
@@ -645,7 +687,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 ray.d = normalize(rotate(eye.camera.rotation, start));
                 ray.L0 = v3(0, 0, 0);
                 ray.T = v3(1, 1, 1);
-                ray.pix = pixel;
+                ray.pix = pixel | (firstLane << 28);
                 ray.active = true;
             }
         } else {
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
         PTSS_STAMP(0);  // ray load / eye-ray generation
 #if PTSS_ABLATE & 2
         Hit h;
-        h.kind = 2; h.idx = (int)(ray.pix % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
+        h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
         const Hit h = closestHit<kFirst>(sc, L, ray.o, ray.d, valid);
@@ -869,15 +911,16 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
         // Not even bounce 0 ran (<= 128 pixels in the frame). Eye rays are made inside bounce 0, so there are
         // none in the pool: do what computeEyeRaysKernel + writeToPixelsKernel would have done to each pixel —
         // two jitter draws, then a sample of radiance 0.
-        if (i < fb.numPixels) {
-            RayRegs ray;
-            loadHome(fb.rngHome, i, ray.rng);
-            (void)ptrng::uniform(ray.rng);
-            (void)ptrng::uniform(ray.rng);
-            ray.L0 = v3(0, 0, 0);
-            ray.pix = i;
-            finishPath(fb, ray);
-        }
+        if (i < fb.numPixels)
+            for (uint32_t l = 0; l < fb.samples; ++l) {
+                RayRegs ray;
+                loadHome(fb.rngHome, l * fb.plane + i, ray.rng);
+                (void)ptrng::uniform(ray.rng);
+                (void)ptrng::uniform(ray.rng);
+                ray.L0 = v3(0, 0, 0);
+                ray.pix = i | (l << 28);
+                finishPath(fb, ray);
+            }
     } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
         for (int s = 0; s < kShards; ++s) {
             const uint32_t n = fb.counts[countIndex(stop, s)];
@@ -901,10 +944,15 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
 // =================================================================================================
 static inline unsigned blocksFor(uint32_t n, unsigned block) { return (n + block - 1) / block; }
 
-hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t capacity, TileMap tile, uint64_t seed,
+hipError_t launchRngInit(hipStream_t st, uint32_t* rngHome, uint32_t plane, uint32_t samples, TileMap tile, uint64_t seed,
                          const uint32_t* jumpTable) {
-    const uint32_t n = (uint32_t)tile.width * (uint32_t)tile.localRows;
-    hipLaunchKernelGGL(rngInitKernel, dim3(blocksFor(n, 256)), dim3(256), 0, st, rngHome, capacity, tile, seed, jumpTable);
+    hipLaunchKernelGGL(rngInitKernel, dim3(blocksFor(plane * samples, 256)), dim3(256), 0, st, rngHome, plane, samples, tile, seed,
+                       jumpTable);
+    return hipGetLastError();
+}
+
+hipError_t launchDisplay(hipStream_t st, const FrameBuffers& fb) {
+    hipLaunchKernelGGL(displayKernel, dim3(blocksFor(fb.numPixels, 256)), dim3(256), 0, st, fb);
     return hipGetLastError();
 }
 

@@ -31,7 +31,8 @@ class PtssError(RuntimeError):
 class RenderConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("seed", C.c_ulonglong), ("maxIterations", C.c_uint),
                 ("device", C.c_int), ("tileRank", C.c_int), ("tileWorld", C.c_int), ("bandRows", C.c_int),
-                ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int)]
+                ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int),
+                ("samplesPerPass", C.c_int)]
 
 
 _host = None
@@ -89,6 +90,7 @@ def device_lib():
         L.ptss_read_float_accumulator.argtypes = [vp, _f32p, C.c_size_t]
         L.ptss_read_pixels.argtypes = [vp, vp, vp, C.c_size_t]
         L.ptss_read_rng_state.argtypes = [vp, C.c_size_t, _u32p]
+        L.ptss_read_rng_state_lane.argtypes = [vp, C.c_size_t, C.c_uint, _u32p]
         L.ptss_synchronize.argtypes = [vp]
         L.ptss_last_pass_ms.argtypes = [vp, _f32p]
         L.ptss_samples_since_reset.argtypes = [vp, C.POINTER(C.c_int)]
@@ -193,7 +195,7 @@ class Renderer:
     """One ptss_context: the reference's ProgramData + device buffers, driven like generateFrame."""
 
     def __init__(self, scene, width, height, max_iterations=15, seed=0x5EED, device=0, tile_rank=0, tile_world=1,
-                 band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False):
+                 band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1):
         L = device_lib()
         cfg = RenderConfig()
         _check(L.ptss_default_config(C.byref(cfg)))
@@ -205,6 +207,7 @@ class Renderer:
         cfg.syncEachFrame = 1 if sync_each_frame else 0
         cfg.floatAccumulator = 1 if float_accumulator else 0
         cfg.timeKernels = 1 if time_kernels else 0
+        cfg.samplesPerPass = samples_per_pass
         self.cfg = cfg
         self._scene = scene  # keep the arrays alive during create
         self._ctx = C.c_void_p()
@@ -304,9 +307,9 @@ class Renderer:
         _check(device_lib().ptss_read_pixels(self._ctx, dev_pixels, out.ctypes.data_as(C.c_void_p), self.local_pixels))
         return out
 
-    def rng_state(self, local_pixel):
+    def rng_state(self, local_pixel, lane=0):
         out = np.empty(6, dtype=np.uint32)
-        _check(device_lib().ptss_read_rng_state(self._ctx, local_pixel, out.ctypes.data_as(_u32p)))
+        _check(device_lib().ptss_read_rng_state_lane(self._ctx, local_pixel, lane, out.ctypes.data_as(_u32p)))
         return out
 
     def last_pass_ms(self):

@@ -39,6 +39,11 @@ typedef struct ptss_render_config {
     int syncEachFrame;     /* 1: block on the stop event and record ms each frame, as CudaTracer.cu:639-642 */
     int floatAccumulator;  /* 1: also keep a linear float32 sum of radiance0 per pixel */
     int timeKernels;       /* 1: bracket every bounce kernel with HIP events (bench.py roofline) */
+    /* Extension, default 1 = the reference: S independent samples per pixel per
+     * ptss_generate_frame call. Sample lane l of global pixel g owns XORWOW subsequence g*S + l; every sample
+     * is still tone-mapped on its own before it is summed (CudaTracer.cu:72-92); the display divides by
+     * S*(ticks - lastResetTick + 1). Lets one launch carry S times the rays (multi-GPU shards stay busy). 1..16. */
+    int samplesPerPass;
 } ptss_render_config;
 
 /* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */
@@ -81,7 +86,8 @@ int ptss_local_rows(const ptss_context* ctx, int* rows, int cap, int* count); /*
 int ptss_read_accumulator(ptss_context* ctx, uint32_t* host_uint3, size_t count);       /* 3 * local pixels */
 int ptss_read_float_accumulator(ptss_context* ctx, float* host_float3, size_t count);   /* 3 * local pixels */
 int ptss_read_pixels(ptss_context* ctx, const ptss_uchar4* dev_pixels, ptss_uchar4* host, size_t count);
-int ptss_read_rng_state(ptss_context* ctx, size_t local_pixel, uint32_t* out6);         /* v0..v4, d */
+int ptss_read_rng_state(ptss_context* ctx, size_t local_pixel, uint32_t* out6);         /* v0..v4, d (sample lane 0) */
+int ptss_read_rng_state_lane(ptss_context* ctx, size_t local_pixel, unsigned int lane, uint32_t* out6);
 int ptss_synchronize(ptss_context* ctx);
 
 /* ≙ the "Rays per pixel / Time per pass" line (CudaTracer.cu:641-646). */

@@ -138,6 +138,7 @@ struct Ray {  // RenderStructs.h:24-39
     vec3 radiance1;
     int pixelOffset;
     bool active;
+    int lane;  // extension: sample lane 0..S-1 (S = samplesPerPass; the reference has S = 1)
 };
 
 inline Ray makeRay(vec3 origin, vec3 direction) {
@@ -148,6 +149,7 @@ inline Ray makeRay(vec3 origin, vec3 direction) {
     r.radiance1 = v3(1, 1, 1);
     r.pixelOffset = 0;
     r.active = true;
+    r.lane = 0;
     return r;
 }
 
@@ -522,10 +524,12 @@ struct oracle_ctx {
     bool resetTicksThisFrame;
     int lastResetTick;
     int literalSlotRng;  // fidelity probe: slot-bound RNG + numRays/96 truncation
+    int samples;         // extension: S independent sample lanes per pixel per frame; 1 = the reference
     std::vector<Ray> rays;
     std::vector<CurandState> curandStates;
     std::vector<uint32_t> totalPixelColors;  // uint3 per pixel
-    std::vector<float> floatSum;             // linear sum of radiance0 per pixel (extra, §9.1)
+    std::vector<float> floatSum;             // linear sum of radiance0 per STREAM (lane * N + pixel) (extra, §9.1)
+    std::vector<float> floatSumPixel;        // the same summed over lanes in lane order (filled on request)
     std::vector<float> lastRadiance0;        // radiance0 of the last frame, by pixel
     std::vector<uint32_t> liveCounts;        // rays entering each bounce of the last frame
     uint64_t totalRayBounces;
@@ -534,8 +538,9 @@ struct oracle_ctx {
 extern "C" {
 
 oracle_ctx* oracle_create(const ptss_scene_desc* scene, int width, int height, unsigned long long seed,
-                          unsigned maxIterations, int literalSlotRng) {
-    if (!scene || width <= 0 || height <= 0) return nullptr;
+                          unsigned maxIterations, int literalSlotRng, int samplesPerPass) {
+    if (!scene || width <= 0 || height <= 0 || samplesPerPass < 1 || samplesPerPass > 16) return nullptr;
+    if (literalSlotRng && samplesPerPass != 1) return nullptr;
     oracle_ctx* c = new oracle_ctx();
     c->data.defaultColor = scene->defaultColor;
     c->data.spheres.assign(scene->spheres, scene->spheres + scene->numSpheres);
@@ -555,17 +560,24 @@ oracle_ctx* oracle_create(const ptss_scene_desc* scene, int width, int height, u
     c->resetTicksThisFrame = true;  // CudaTracer.cu:717
     c->lastResetTick = 0;
     c->literalSlotRng = literalSlotRng;
+    c->samples = samplesPerPass;
     const size_t n = (size_t)width * height;
-    c->rays.resize(n);
-    c->curandStates.resize(n);
+    const size_t m = n * (size_t)samplesPerPass;  // streams = rays per frame
+    c->rays.resize(m);
+    c->curandStates.resize(m);
     c->totalPixelColors.assign(3 * n, 0u);
-    c->floatSum.assign(3 * n, 0.0f);
-    c->lastRadiance0.assign(3 * n, 0.0f);
+    c->floatSum.assign(3 * m, 0.0f);
+    c->floatSumPixel.assign(3 * n, 0.0f);
+    c->lastRadiance0.assign(3 * m, 0.0f);
     c->totalRayBounces = 0;
     (void)sequencePowers();
     // curandSetupKernel, CudaTracer.cu:22-29: same seed, sequence = slot
 #pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)n; ++i) curand_init(seed, (uint32_t)i, &c->curandStates[i]);
+    // stream (lane l, pixel p) is stored at l * N + p and owns subsequence p * S + l
+    for (long i = 0; i < (long)m; ++i) {
+        const long l = i / (long)n, pix = i % (long)n;
+        curand_init(seed, (uint32_t)(pix * samplesPerPass + l), &c->curandStates[i]);
+    }
     return c;
 }
 
@@ -592,6 +604,8 @@ void oracle_request_reset(oracle_ctx* c) { c->resetTicksThisFrame = true; }
 void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
     const int W = c->width, H = c->height;
     const long N = (long)W * H;
+    const int S = c->samples;
+    const long M = N * S;
 
     if (c->resetTicksThisFrame) {  // :602-608 + clearPixels :31-49
         c->lastResetTick = ticks;
@@ -603,14 +617,16 @@ void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
 
     // computeEyeRaysKernel :51-61
 #pragma omp parallel for schedule(static)
-    for (long offset = 0; offset < N; ++offset) {
+    for (long slot = 0; slot < M; ++slot) {
+        const long offset = slot % N;
         const int x = (int)(offset % W), y = (int)(offset / W);
-        Ray ray = computeEyeRay(x, y, W, H, c->camera, c->curandStates[offset]);
+        Ray ray = computeEyeRay(x, y, W, H, c->camera, c->curandStates[slot]);
         ray.pixelOffset = (int)offset;
-        c->rays[offset] = ray;
+        ray.lane = (int)(slot / N);
+        c->rays[slot] = ray;
     }
 
-    long numRays = N;
+    long numRays = M;
     const unsigned numIterations = c->usePathTracer ? c->maxIterations : 1;  // :620
     c->liveCounts.assign(numIterations, 0u);
     std::vector<Ray> scratch;
@@ -622,7 +638,7 @@ void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
 #pragma omp parallel for schedule(dynamic, 256)
         for (long slot = 0; slot < launched; ++slot) {
             Ray& ray = c->rays[slot];
-            CurandState& st = c->literalSlotRng ? c->curandStates[slot] : c->curandStates[ray.pixelOffset];
+            CurandState& st = c->literalSlotRng ? c->curandStates[slot] : c->curandStates[(long)ray.lane * N + ray.pixelOffset];
             pathTraceOne(c->data, ray, st, isLast);
         }
         if (!isLast) {  // :626-632, stable
@@ -637,31 +653,38 @@ void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
         }
     }
 
-    // writeToPixelsKernel :63-104 over all N slots
+    // writeToPixelsKernel :63-104 over all slots: every sample is tone-mapped on its own, then summed
     const int sample = ticks - c->lastResetTick;
-    const float inverseTicks = 1.f / (sample + 1);
-#pragma omp parallel for schedule(static)
-    for (long offset = 0; offset < N; ++offset) {
-        const Ray& ray = c->rays[offset];
-        const long p = ray.pixelOffset;
+    const float inverseTicks = 1.f / (float)(S * (sample + 1));  // S = 1: 1.f / (ticks + 1), :94
+    for (long slot = 0; slot < M; ++slot) {
+        const Ray& ray = c->rays[slot];
+        const long p = ray.pixelOffset, stream = (long)ray.lane * N + p;
         const float rad[3] = {ray.radiance0.x, ray.radiance0.y, ray.radiance0.z};
-        unsigned char out[3];
         for (int ch = 0; ch < 3; ++ch) {
-            uint32_t total = c->totalPixelColors[3 * p + ch] + quantizeSample(rad[ch]);
-            c->totalPixelColors[3 * p + ch] = total;
-            out[ch] = (unsigned char)(total * inverseTicks + 0.5f);
-            c->floatSum[3 * p + ch] += rad[ch];
-            c->lastRadiance0[3 * p + ch] = rad[ch];
+            c->totalPixelColors[3 * p + ch] += quantizeSample(rad[ch]);
+            c->floatSum[3 * stream + ch] += rad[ch];
+            c->lastRadiance0[3 * stream + ch] = rad[ch];
         }
-        pixels[p].x = out[0];
-        pixels[p].y = out[1];
-        pixels[p].z = out[2];
+    }
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < N; ++p) {
+        pixels[p].x = (unsigned char)(c->totalPixelColors[3 * p + 0] * inverseTicks + 0.5f);
+        pixels[p].y = (unsigned char)(c->totalPixelColors[3 * p + 1] * inverseTicks + 0.5f);
+        pixels[p].z = (unsigned char)(c->totalPixelColors[3 * p + 2] * inverseTicks + 0.5f);
         pixels[p].w = 255;
     }
 }
 
 const uint32_t* oracle_accumulator(const oracle_ctx* c) { return c->totalPixelColors.data(); }
-const float* oracle_float_sum(const oracle_ctx* c) { return c->floatSum.data(); }
+const float* oracle_float_sum(oracle_ctx* c) {  // per pixel: the per-stream sums added in lane order 0..S-1
+    const long N = (long)c->width * c->height;
+    for (long k = 0; k < 3 * N; ++k) {
+        float acc = 0.0f;
+        for (int l = 0; l < c->samples; ++l) acc = acc + c->floatSum[3 * (long)l * N + k];
+        c->floatSumPixel[k] = acc;
+    }
+    return c->floatSumPixel.data();
+}
 const float* oracle_last_radiance0(const oracle_ctx* c) { return c->lastRadiance0.data(); }
 int oracle_live_counts(const oracle_ctx* c, uint32_t* out, int cap) {
     const int n = (int)c->liveCounts.size();
@@ -669,8 +692,8 @@ int oracle_live_counts(const oracle_ctx* c, uint32_t* out, int cap) {
     return n;
 }
 unsigned long long oracle_total_ray_bounces(const oracle_ctx* c) { return c->totalRayBounces; }
-void oracle_rng_state(const oracle_ctx* c, long pixel, uint32_t* out6) {
-    const CurandState& s = c->curandStates[pixel];
+void oracle_rng_state(const oracle_ctx* c, long pixel, int lane, uint32_t* out6) {
+    const CurandState& s = c->curandStates[(long)lane * c->width * c->height + pixel];
     for (int i = 0; i < 5; ++i) out6[i] = s.v[i];
     out6[5] = s.d;
 }

@@ -29,7 +29,7 @@ def lib():
             raise RuntimeError(f"{LIB} missing: run `python __graft_entry__.py build`")
         L = C.CDLL(LIB)
         vp = C.c_void_p
-        L.oracle_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int]
+        L.oracle_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int, C.c_int]
         L.oracle_create.restype = vp
         L.oracle_destroy.argtypes = [vp]
         L.oracle_destroy.restype = None
@@ -54,7 +54,7 @@ def lib():
         L.oracle_live_counts.argtypes = [vp, _u32p, C.c_int]
         L.oracle_total_ray_bounces.argtypes = [vp]
         L.oracle_total_ray_bounces.restype = C.c_ulonglong
-        L.oracle_rng_state.argtypes = [vp, C.c_long, _u32p]
+        L.oracle_rng_state.argtypes = [vp, C.c_long, C.c_int, _u32p]
         L.oracle_rng_state.restype = None
         L.oracle_probe_sphere.argtypes = [C.POINTER(Sphere), _f32p, C.c_float, _f32p]
         L.oracle_probe_triangle.argtypes = [C.POINTER(Triangle), _f32p, C.c_float, _f32p]
@@ -103,11 +103,12 @@ def _f3(v):
 class Oracle:
     """CPU generateFrame over a full frame. scene_desc: a ptss_types.SceneDesc (kept alive by the caller)."""
 
-    def __init__(self, scene_desc, width, height, max_iterations=15, seed=0x5EED, literal_slot_rng=False):
+    def __init__(self, scene_desc, width, height, max_iterations=15, seed=0x5EED, literal_slot_rng=False,
+                 samples_per_pass=1):
         self.width, self.height = width, height
         self.n = width * height
         self._c = lib().oracle_create(C.byref(scene_desc), width, height, seed, max_iterations,
-                                      1 if literal_slot_rng else 0)
+                                      1 if literal_slot_rng else 0, samples_per_pass)
         if not self._c:
             raise RuntimeError("oracle_create failed")
         self.pixels_host = np.zeros((self.n, 4), dtype=np.uint8)
@@ -162,9 +163,9 @@ class Oracle:
     def total_ray_bounces(self):
         return int(lib().oracle_total_ray_bounces(self._c))
 
-    def rng_state(self, pixel):
+    def rng_state(self, pixel, lane=0):
         out = np.empty(6, dtype=np.uint32)
-        lib().oracle_rng_state(self._c, pixel, out.ctypes.data_as(_u32p))
+        lib().oracle_rng_state(self._c, pixel, lane, out.ctypes.data_as(_u32p))
         return out
 
     def probe_shade(self, point, normal, material_idx, seed=1):

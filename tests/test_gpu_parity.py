@@ -109,3 +109,31 @@ def test_tiny_frame_below_the_guard():
     assert np.array_equal(r.pixels(), o.pixels())
     assert np.array_equal(r.rng_state(5), o.rng_state(5))
     r.close()
+
+
+@pytest.mark.parametrize("preset,w,h,bounces,ticks,S", [
+    ("cornell", 96, 64, 4, 5, 2),
+    ("mixed", 80, 45, 8, 4, 4),
+    ("default", 33, 17, 6, 3, 16),     # ragged frame, maximum lane count
+    ("cornell", 8, 8, 4, 3, 2),        # 128 rays: at the loop guard (flush path with lanes)
+    ("cornell", 6, 6, 4, 2, 3),        # 108 rays, non-power-of-two S: nothing runs, every stream still advances
+])
+def test_samples_per_pass_extension_matches_oracle(preset, w, h, bounces, ticks, S):
+    """cfg.samplesPerPass = S: S independent streams per pixel per frame; the oracle models the
+    same definition (stream (p, l) owns subsequence p*S + l), so parity stays bit-exact."""
+    scene = ptss.Scene(preset)
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True, samples_per_pass=S)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=S)
+    for _ in range(ticks):
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts())
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert r.accumulator().max() <= 255 * S * ticks
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert _eq_nan(r.float_accumulator(), o.float_sum())
+    assert r.total_ray_bounces() == o.total_ray_bounces()
+    for p in (0, w * h - 1):
+        for lane in (0, S - 1):
+            assert np.array_equal(r.rng_state(p, lane), o.rng_state(p, lane))
+    r.close()

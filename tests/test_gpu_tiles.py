@@ -12,13 +12,13 @@ import tiles
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,band", [(2, 8), (3, 4), (8, 8)])
-def test_tiles_reassemble_to_the_oracle_frame(world, band):
+@pytest.mark.parametrize("world,band,S", [(2, 8, 1), (3, 4, 1), (8, 8, 1), (4, 8, 4)])
+def test_tiles_reassemble_to_the_oracle_frame(world, band, S):
     w, h, bounces, spp = 64, 45, 5, 4
     scene = ptss.Scene("mixed")
-    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=S)
     rs = [ptss.Renderer(scene, w, h, max_iterations=bounces, tile_rank=k, tile_world=world, band_rows=band,
-                        float_accumulator=True) for k in range(world)]
+                        float_accumulator=True, samples_per_pass=S) for k in range(world)]
     for _ in range(spp):
         o.generate_frame()
         for r in rs:

@@ -90,3 +90,26 @@ def test_literal_slot_rng_probe_differs_only_statistically():
     ma, mb = a.accumulator().mean(0) / 24, b.accumulator().mean(0) / 24
     assert np.abs(ma - mb).max() < 6.0     # same mean image brightness to within noise
     assert b.live_counts()[0] == (48 * 48 // 96) * 96
+
+
+def test_samples_per_pass_extension_semantics():
+    """S sample lanes per pixel (extension; S = 1 is the reference): lane l of pixel p owns subsequence p*S + l,
+    every sample is tone-mapped on its own, the display divides by S*(ticks+1)."""
+    scene = ptss.Scene("cornell")
+    w = h = 24
+    a = oracle.Oracle(scene.desc, w, h, max_iterations=4, samples_per_pass=1)
+    b = oracle.Oracle(scene.desc, w, h, max_iterations=4, samples_per_pass=4)
+    assert np.array_equal(b.rng_state(5, 0), oracle.probe_rng(0x5EED, 5 * 4 + 0, 0)[0])
+    assert np.array_equal(b.rng_state(5, 3), oracle.probe_rng(0x5EED, 5 * 4 + 3, 0)[0])
+    assert np.array_equal(a.rng_state(5), oracle.probe_rng(0x5EED, 5, 0)[0])
+    for _ in range(8):
+        a.generate_frame()
+    for _ in range(2):
+        b.generate_frame()
+    assert b.live_counts()[0] == 4 * w * h
+    acc_a, acc_b = a.accumulator(), b.accumulator()           # 8 samples per pixel each, different streams
+    assert acc_b.max() <= 255 * 8 and not np.array_equal(acc_a, acc_b)
+    assert abs(acc_a.mean() - acc_b.mean()) / acc_a.mean() < 0.05
+    px = b.pixels()
+    assert np.array_equal(px[:, :3], (acc_b * np.float32(1.0) / np.float32(8) + np.float32(0.5)).astype(np.uint8)) or \
+        np.array_equal(px[:, :3], (acc_b * (np.float32(1.0) / np.float32(8)) + np.float32(0.5)).astype(np.uint8))

@@ -1,0 +1,33 @@
+"""Per-rank frame time of the N-way pixel-tile shard, measured on ONE GPU by rendering rank 0's tile only
+(the ranks are independent until the final gather, so this is what each GPU of an N-GPU run does).
+   python tools/scale_emulate.py [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cuda-path-tracer-ss_amd"))
+import ptss  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+scene = ptss.Scene("mixed")
+base = None
+for world in (1, 2, 4, 8):
+    r = ptss.Renderer(scene, 1920, 1080, max_iterations=8, tile_rank=0, tile_world=world, band_rows=8, sync_each_frame=False,
+                      samples_per_pass=S)
+    for _ in range(30):
+        r.generate_frame()
+    r.synchronize()
+    r0 = r.total_ray_bounces()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.generate_frame()
+    r.synchronize()
+    dt = time.perf_counter() - t0
+    rays = r.total_ray_bounces() - r0
+    ms = dt / steps * 1e3
+    base = base or ms
+    print("S=%d " % S + "world %d: %.4f ms/step per rank, %7.1f Mrays/s per rank -> predicted aggregate %8.1f Mrays/s, speedup %.2fx, efficiency %.0f %%"
+          % (world, ms, rays / dt / 1e6, rays / dt / 1e6 * world, base / ms, 100 * base / ms / world))
+    r.close()
