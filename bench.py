@@ -4,11 +4,13 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path = one sample per pixel through the whole bounce loop
-(eye rays -> up to 8 x [intersect + NEE + scatter + compaction] -> accumulate), i.e. one call of
-the generateFrame drop-in (reference CudaTracer.cu:587-647). Workload at every N: BASELINE.json
-configs[2]/[3] — 1920x1080, scene preset "mixed" (22 spheres + 16 triangles, Lambert / Phong /
-Cook-Torrance / glass / mirror), 8 bounces; K defaults to the config's 2000 spp. For N > 1 the
+A "step" is one pass of the hot path = one call of the generateFrame drop-in (reference
+CudaTracer.cu:587-647): eye rays -> up to 8 x [intersect + NEE + scatter + compaction] -> accumulate,
+for S = --samples-per-pass independent samples per pixel (cfg.samplesPerPass; S = 1 is the reference's one
+sample per tick; the default S = 16 x 125 passes is the config's 2000 spp, and keeps every launch — and every
+shard of a multi-GPU run — wide enough to fill the chip; the image does not depend on N). Workload at every
+N: BASELINE.json configs[2]/[3] — 1920x1080, scene preset "mixed" (22 spheres + 16 triangles, Lambert /
+Phong / Cook-Torrance / glass / mirror), 8 bounces. For N > 1 the
 SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
 so total work is fixed ("strong" scaling); the integer accumulators are gathered to rank 0 with one
 RCCL gather inside the timed region.
@@ -61,7 +63,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=125)
+    ap.add_argument("--samples-per-pass", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -92,7 +95,7 @@ def main():
     scene = ptss.Scene(PRESET)
     r = ptss.Renderer(scene, WIDTH, HEIGHT, max_iterations=BOUNCES, seed=SEED, device=local_rank,
                       tile_rank=rank, tile_world=world, band_rows=BAND_ROWS, sync_each_frame=False,
-                      time_kernels=not args.no_kernel_timing)
+                      time_kernels=not args.no_kernel_timing, samples_per_pass=args.samples_per_pass)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     # torch owns the buffers that leave the renderer: accumulator (gathered) and display pixels
@@ -133,7 +136,7 @@ def main():
     if rank == 0 and dist is not None:   # untimed sanity: the gathered tiles tile the frame
         sizes = [len(ptss.tile_rows(HEIGHT, BAND_ROWS, k, world)) * WIDTH for k in range(world)]
         frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], WIDTH, HEIGHT, BAND_ROWS)
-        assert frame.shape == (WIDTH * HEIGHT, 3) and int(frame.max()) <= 255 * (args.steps + args.warmup)
+        assert frame.shape == (WIDTH * HEIGHT, 3) and int(frame.max()) <= 255 * (args.steps + args.warmup) * args.samples_per_pass
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
     stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device="cuda")
@@ -162,11 +165,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"configs[2]: {WIDTH}x{HEIGHT} '{PRESET}' preset (22 spheres, 16 triangles, "
-                                   f"Lambert/Phong/Cook-Torrance/glass/mirror), {BOUNCES} bounces, {args.steps} spp",
+                                   f"Lambert/Phong/Cook-Torrance/glass/mirror), {BOUNCES} bounces, "
+                                   f"{args.steps * args.samples_per_pass} spp = {args.steps} passes x {args.samples_per_pass} "
+                                   f"sample lanes per pixel",
+                       "samples_per_pass": args.samples_per_pass,
                        "sharding": f"{world} rank(s), interleaved {BAND_ROWS}-row pixel bands"
                                    + (", one RCCL gather of the uint3 accumulator" if world > 1 else ""),
                        "seed": SEED},
-            "mpaths_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 2),
+            "mpaths_per_s": round(WIDTH * HEIGHT * args.steps * args.samples_per_pass / elapsed / 1e6, 2),
             "ray_bounces": int(rays),
         }
         if kms > 0:
