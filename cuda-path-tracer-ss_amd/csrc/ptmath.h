@@ -84,6 +84,57 @@ PTM_HD uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 PTM_HD float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 PTM_HD float inf() { return u2f(0x7f800000u); }
 PTM_HD float qnan() { return u2f(0x7fc00000u); }
+
+// div(a, b) = a / b, correctly rounded (IEEE) on both sides. Device fast path (Markstein): with r = RN(1/b) from the
+// rcp fast path, q0 = a*r, q = fma(fma(-b, q0, a), r, q0). Bit-identical to the IEEE quotient for ALL 2^46 pairs of
+// float32 mantissas (tests/csrc/math_exhaustive.hip; power-of-two scaling is exact, so mantissas decide), as long as
+// nothing under- or overflows: guarded to |a|, |b| in [2^-60, 2^60); everything else (zeros, infinities, NaNs, extreme
+// exponents) takes the IEEE sequence through a wave-uniform escape.
+#if defined(__HIP_DEVICE_COMPILE__)
+PTM_HD bool div_in_range(float x) {
+    const float ax = __builtin_fabsf(x);
+    return ax >= 8.6736174e-19f /* 2^-60 */ && ax < 1.1529215e18f /* 2^60 */;
+}
+PTM_HD float rcp_core(float b) {  // only for operands already known to be in range
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+PTM_HD float div_core(float a, float b, float r) {
+    const float q0 = a * r;
+    const float rem = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(rem, r, q0);
+}
+#endif
+PTM_HD float div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = div_core(a, b, rcp_core(b));
+    const bool inRange = div_in_range(a) && div_in_range(b);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) q = inRange ? q : a / b;
+    return q;
+#else
+    return a / b;
+#endif
+}
+// three numerators over one denominator (glm's vec3 / float is three divisions): one reciprocal serves all
+PTM_HD void div3(float ax, float ay, float az, float b, float& qx, float& qy, float& qz) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = rcp_core(b);
+    qx = div_core(ax, b, r);
+    qy = div_core(ay, b, r);
+    qz = div_core(az, b, r);
+    const bool inRange = div_in_range(b) && div_in_range(ax) && div_in_range(ay) && div_in_range(az);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) {
+        qx = inRange ? qx : ax / b;
+        qy = inRange ? qy : ay / b;
+        qz = inRange ? qz : az / b;
+    }
+#else
+    qx = ax / b;
+    qy = ay / b;
+    qz = az / b;
+#endif
+}
 // glm::max(a,b) = (a < b) ? b : a ; glm::min(a,b) = (b < a) ? b : a  (ordered compares, NaN-stable)
 PTM_HD float max(float a, float b) { return (a < b) ? b : a; }
 PTM_HD float min(float a, float b) { return (b < a) ? b : a; }
@@ -117,7 +168,7 @@ PTM_HD void sincos(float x, float& s, float& c) {
 PTM_HD float tan(float x) {
     float s, c;
     sincos(x, s, c);
-    return s / c;
+    return div(s, c);
 }
 
 // atan, Cephes atanf reduction (tan 3pi/8, tan pi/8) + degree-4 odd polynomial.
@@ -130,7 +181,7 @@ PTM_HD float atan(float x) {
         t = -rcp(ax);
     } else if (ax > 0.4142135623730950f) {
         y = 0.7853981633974483f;
-        t = (ax - 1.0f) / (ax + 1.0f);
+        t = div(ax - 1.0f, ax + 1.0f);
     } else {
         y = 0.0f;
         t = ax;
@@ -233,7 +284,11 @@ PTM_HD vec3 operator-(vec3 a) { return vec3{-a.x, -a.y, -a.z}; }
 PTM_HD vec3 operator*(vec3 a, vec3 b) { return vec3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 PTM_HD vec3 operator*(vec3 a, float s) { return vec3{a.x * s, a.y * s, a.z * s}; }
 PTM_HD vec3 operator*(float s, vec3 a) { return vec3{a.x * s, a.y * s, a.z * s}; }
-PTM_HD vec3 operator/(vec3 a, float s) { return vec3{a.x / s, a.y / s, a.z / s}; }
+PTM_HD vec3 operator/(vec3 a, float s) {
+    vec3 q;
+    ptm::div3(a.x, a.y, a.z, s, q.x, q.y, q.z);
+    return q;
+}
 // o + v*s with one rounding per component (the contraction nvcc applies to `o + d * t`)
 PTM_HD vec3 madd(vec3 v, float s, vec3 o) { return vec3{ptm::fma(v.x, s, o.x), ptm::fma(v.y, s, o.y), ptm::fma(v.z, s, o.z)}; }
 // o + a*b component-wise, one rounding

@@ -366,15 +366,15 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         n1 = mMisc.y;
         n2 = 1.0f;
     }
-    const float n = n1 / n2;
+    const float n = ptm::div(n1, n2);
     const float sinT2 = n * n * (1.0f - cosI * cosI);
 
     // computeFresnelForReflectance :457-472
     float fresnelReflective = 1.0f;
     if (!(sinT2 > 1.0f)) {
         const float cosT = ptm::sqrt(1.0f - sinT2);
-        const float r_s = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
-        const float r_p = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+        const float r_s = ptm::div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
+        const float r_p = ptm::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
         fresnelReflective = (r_s * r_s + r_p * r_p) * 0.5f;
     }
 
@@ -407,7 +407,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
                 const float nl = ptm::abs(dot(normal, ray.d));
                 const float vh = ptm::abs(dot(incident, half));
                 const float nv = ptm::abs(cosI);
-                const float geometric = ptm::min(ptm::min(1.0f, 2 * nh * nl / vh), 2 * nh * nv / vh);
+                const float geometric = ptm::min(ptm::min(1.0f, ptm::div(2 * nh * nl, vh)), ptm::div(2 * nh * nv, vh));
                 return xyz(mSpecular) * geometric / nv;
             }
             // reflRay(ray, surfel, cosI) :496-503
