@@ -9,15 +9,17 @@
 //   flushKernel     <- writeToPixelsKernel for rays still alive when the loop guard stops the frame
 //                                                   CudaTracer.cu:622, :63-104
 //
-// Design: one ray per lane; ray state in SoA planes (coalesced 256-B wave accesses),
-// pools cut into kShards regions with one live-ray counter each; the whole scene staged once per
-// workgroup into LDS and read by broadcast; divergence is attacked at WAVE level, without
-// barriers: sphere hits are resolved from per-lane candidate bit masks, and the shadow rays of
-// two lights at a time are regrouped densely through a wave-private LDS queue; live rays are
-// compacted in the kernel that traces them (64-bit ballot + lane rank + one atomic per workgroup
-// on a device-resident counter, so the host never reads a ray count inside a frame); a path that
-// ends tone-maps into the integer accumulator right there and parks its XORWOW state in the
-// per-pixel home slot. No MFMA: there is no dense contraction in this path.
+// Design: one ray per lane; ray state in SoA planes (coalesced 256-B wave accesses), pools cut
+// into kShards regions with one live-ray counter each; the whole scene staged once per workgroup into LDS
+// and read by broadcast; divergence is attacked at WAVE level, without barriers: sphere hits are resolved
+// from per-lane candidate bit masks, triangle tests exit wave-uniformly, and the shadow rays of two lights
+// at a time are regrouped densely through a wave-private LDS queue; live rays are compacted by the wave
+// that traced them (64-bit ballot + popcount lane rank + one returning atomic per wave on the shard's
+// device-resident counter, issued before the tone-mapping of the finished lanes so its round trip hides),
+// so the host never reads a ray count inside a frame; a path that ends tone-maps into the integer
+// accumulator right there and parks its XORWOW state in the per-pixel home record. Bounce 0 makes its own
+// eye rays. Reciprocals, square roots and divisions use hardware approximation + one fma correction where
+// that is proven bit-identical to IEEE (ptmath.h). No MFMA: there is no dense contraction in this path.
 //
 // Arithmetic mirrors oracle/oracle.cpp operation for operation (ptmath.h; -ffp-contract=off);
 // every restructuring below is argued exact where it is made.
