@@ -326,11 +326,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
 
     std::vector<float4> blob;
     packScene(*scene, c->layout, blob);
-    const size_t ldsBytes = (size_t)c->layout.totalVec4 * sizeof(float4);
-    if (ptss::bounceLdsBytes(c->layout, true) > 160 * 1024) {
-        delete c;
-        return fail(PTSS_EINVAL, "scene does not fit the 160 KiB LDS staging budget");
-    }
+    // Scenes whose image fits the default 64 KiB dynamic-LDS window are staged in LDS; larger ones are read in place
+    // (wave-uniform scalar loads + per-lane gathers from global memory) — same kernel, same results, no size limit.
+    const bool sceneFitsLds = ptss::bounceLdsBytes(c->layout, true) <= 64 * 1024;
 
 #define CREATE_TRY(expr)                                  \
     do {                                                  \
@@ -386,9 +384,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     // Scene access path: staged into LDS (north_star). The scalar-load variant (wave-uniform
     // s_load through the scalar cache) is kept for A/B runs via PTSS_SCENE_PATH=scalar; on the
     // 38-primitive "mixed" scene it measured 16 % slower (profiles/README.md, r01).
-    c->sceneInLds = true;
+    c->sceneInLds = sceneFitsLds;
     if (const char* e = getenv("PTSS_SCENE_PATH")) {
-        if (!strcmp(e, "lds")) c->sceneInLds = true;
+        if (!strcmp(e, "lds")) c->sceneInLds = sceneFitsLds;
         if (!strcmp(e, "scalar")) c->sceneInLds = false;
     }
     c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
@@ -432,6 +430,7 @@ int ptss_destroy(ptss_context* c) {
 int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     if (!c) return fail(PTSS_EINVAL, "ctx is null");
     hipStream_t st = c->stream;
+    HIP_TRY(hipSetDevice(c->cfg.device));  // contexts of several devices may live in one thread
     c->lastTicks = ticks;
     if (c->numPixels == 0) {  // a rank whose tile is empty (more ranks than row bands): nothing to render
         if (c->resetTicksThisFrame) c->lastResetTick = ticks;

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     float4* work = lds + (kSceneInLds ? L.totalVec4 : 0);
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(work);
+    [[maybe_unused]] uint32_t* scratch = reinterpret_cast<uint32_t*>(work);  // PTSS_WAVE_COMPACT=0 variant only
     float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
     uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
     uint32_t* wqAnswer = wqOwner + kQueueCap;  // [kNeeLights][64]

@@ -137,3 +137,50 @@ def test_samples_per_pass_extension_matches_oracle(preset, w, h, bounces, ticks,
         for lane in (0, S - 1):
             assert np.array_equal(r.rng_state(p, lane), o.rng_state(p, lane))
     r.close()
+
+
+def _custom_scene(num_spheres, seed=7):
+    """A scene assembled straight from the C records (no preset): random small spheres of four material classes inside a
+    lit box — what a caller with its own Scene builder would hand to ptss_create."""
+    import ctypes as C
+    from ptss_types import AreaLight, Material, SceneDesc, Sphere, Triangle
+    base = ptss.Scene("cornell")                      # borrow the box (14 triangles, light) and its 7 materials
+    rng = np.random.default_rng(seed)
+    mats = (Material * base.desc.numMaterials)(*base.materials)
+    tris = (Triangle * base.desc.numTriangles)(*base.triangles)
+    lights = (AreaLight * base.desc.numAreaLights)(*base.area_lights)
+    sph = (Sphere * num_spheres)()
+    for i in range(num_spheres):
+        sph[i].position.x, sph[i].position.y = rng.uniform(-3.6, 3.6), rng.uniform(-3.6, 3.6)
+        sph[i].position.z = rng.uniform(-7.7, -1.5)
+        sph[i].radius = rng.uniform(0.03, 0.12)
+        sph[i].materialIdx = int(rng.integers(0, 3)) if i % 3 else 6   # Phong, Phong-glass, white diffuse, mirror
+    d = SceneDesc()
+    d.spheres, d.numSpheres = sph, num_spheres
+    d.triangles, d.numTriangles = tris, len(tris)
+    d.materials, d.numMaterials = mats, len(mats)
+    d.areaLights, d.numAreaLights = lights, len(lights)
+    d.pointLights, d.numPointLights = None, 0
+
+    class Holder:
+        pass
+    h = Holder()
+    h.desc, h.keep = d, (sph, tris, mats, lights, base)
+    return h
+
+
+@pytest.mark.parametrize("num_spheres", [300, 5000])
+def test_custom_scene_from_raw_records(num_spheres):
+    """5,000 spheres (98 KB image) do not fit the 64 KiB LDS window: the context switches to reading the scene in place;
+    300 spheres stay in LDS. Both must match the oracle bit for bit (157 candidate-mask chunks in the large case)."""
+    scene = _custom_scene(num_spheres)
+    w, h, bounces = 40, 24, 4
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces)
+    for _ in range(2):
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts())
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert _eq_nan(r.float_accumulator(), o.float_sum())
+    r.close()
