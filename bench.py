@@ -84,12 +84,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    # Rehearsal knobs (tests / one-GPU boxes only; the driver never sets them): PTSS_BENCH_ONE_GPU=1 puts every rank on
+    # device 0, PTSS_BENCH_BACKEND=gloo swaps RCCL for gloo (collectives staged through host memory).
+    backend = os.environ.get("PTSS_BENCH_BACKEND", "nccl")
+    if os.environ.get("PTSS_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import tiles
     scene = ptss.Scene(PRESET)
@@ -106,9 +115,9 @@ def main():
     if world > 1:
         sizes = [len(ptss.tile_rows(HEIGHT, BAND_ROWS, k, world)) * WIDTH for k in range(world)]
         maxn = max(sizes)
-        send = torch.zeros((maxn, 3), dtype=torch.int32, device="cuda")
+        send = torch.zeros((maxn, 3), dtype=torch.int32, device=coll_dev)
         if rank == 0:
-            gather_list = [torch.zeros((maxn, 3), dtype=torch.int32, device="cuda") for _ in range(world)]
+            gather_list = [torch.zeros((maxn, 3), dtype=torch.int32, device=coll_dev) for _ in range(world)]
 
     def barrier():
         if dist is not None:
@@ -139,7 +148,7 @@ def main():
         assert frame.shape == (WIDTH * HEIGHT, 3) and int(frame.max()) <= 255 * (args.steps + args.warmup) * args.samples_per_pass
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
-    stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
