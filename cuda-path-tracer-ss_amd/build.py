@@ -24,8 +24,13 @@ LIBDIR = os.path.join(HERE, "lib")
 
 FP_FLAGS = ["-ffp-contract=off", "-fno-fast-math"]
 CPU_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-mfma", "-mavx2", "-Wall", "-Wno-unused-function"] + FP_FLAGS
+# -fno-slp-vectorize -fno-vectorize: left alone, hipcc pairs independent float operations into v_pk_{mul,add,fma}_f32
+# (about 190 of them in one bounce kernel, plus the v_mov shuffles that build the register pairs). On gfx950 a packed
+# op issues in ~5.3 SIMD cycles against ~3.3 for each of the two VOP2 ops it replaces (tools/microbench/pk_rate.hip),
+# so the pairing is at best neutral and the shuffles make it a loss: -3 % on the bounce kernel (profiles/README.md).
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt",
-             "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"] + FP_FLAGS
+             "-fno-gpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-fno-vectorize", "-Wall",
+             "-Wno-unused-function"] + FP_FLAGS
 
 
 def _newer(target, sources):
@@ -73,7 +78,8 @@ def build_device(force=False, defines=(), name="libptss.so"):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if force or _newer(out, srcs + _headers()):
-        _run([hipcc] + HIP_FLAGS + ["-D" + d for d in defines] + ["-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
+        extra = os.environ.get("PTSS_EXTRA_HIPFLAGS", "").split()  # A/B measurements only (tools/build_variants.py)
+        _run([hipcc] + HIP_FLAGS + extra + ["-D" + d for d in defines] + ["-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
     return out
 
 

@@ -80,6 +80,21 @@ PTM_HD float rcp(float x) {
     return 1.0f / x;
 #endif
 }
+// rcp for a caller that DISCARDS the result whenever |x| <= 1e-7 (Triangle::intersectRay rejects such determinants,
+// Primitives.h:41-42): every operand whose result is used already lies above the fast path's lower bound 2^-125, so
+// one compare (the upper bound; it also sends NaN to the IEEE sequence) replaces two.
+PTM_HD float rcp_if_above_1em7(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    float out = __builtin_fmaf(e, r0, r0);
+    const bool inRange = __builtin_fabsf(x) < 8.5070592e37f /* 2^126 */;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) out = inRange ? out : 1.0f / x;
+    return out;
+#else
+    return 1.0f / x;
+#endif
+}
 PTM_HD uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 PTM_HD float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 PTM_HD float inf() { return u2f(0x7f800000u); }

@@ -74,7 +74,7 @@ struct ptss_context {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
     int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
-    int gridCap = 0;             // PTSS_GRID_CAP (measurement only)
+    int gridCap = 1280;          // workgroups per shard at most (PTSS_GRID_CAP overrides; 0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
     uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
@@ -486,14 +486,16 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         // grid: one tile per workgroup for the expected live count (+1.5 %), never more than the frame;
         // the kernel grid-strides, so a low hint costs time, not correctness
         int blocks = c->maxBlocks;
-        if (c->gridCap > 0) {  // PTSS_GRID_CAP=<blocks per shard>: measurement knob, persistent-style grids
-            if (c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
-        } else if (i > 0 && c->haveHint) {
+        if (i > 0 && c->haveHint) {
             // tiles for the fullest shard (+1.5 %), times kShards (workgroup b serves shard b % kShards)
             const unsigned long long tilesPerShard = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
             const unsigned long long want = tilesPerShard * ptss::kShards;
             if (want < (unsigned long long)blocks) blocks = (int)want;
         }
+        // Launches wider than 16 resident rounds (256 CUs x 5 workgroups) stop growing: beyond that a workgroup walks
+        // several tiles and stages the scene into LDS once for all of them (+1.7 % at 16 samples per pass; the cap never
+        // binds at 1080p with one sample per pass). PTSS_GRID_CAP=<workgroups per shard> overrides, 0 = no cap.
+        if (c->gridCap > 0 && c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
         EventPair ev{nullptr, nullptr};
         if (c->cfg.timeKernels) {
             if (c->evFree.empty()) {

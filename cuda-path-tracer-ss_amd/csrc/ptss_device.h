@@ -34,13 +34,17 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_BLOCK 256
 #endif
 #ifndef PTSS_MINWAVES
-#define PTSS_MINWAVES 5   // __launch_bounds__ waves/SIMD: caps the bounce kernel at 96 VGPRs (measured +7 % over uncapped)
+#define PTSS_MINWAVES 6   // __launch_bounds__ waves/SIMD: caps the bounce kernel at 80 VGPRs. With the vectorisers off (build.py)
+                          // that fits with at most 8 B of scratch: +6 % over 5 waves / 96 VGPRs; 7 waves (72) spills and loses 1 %
 #endif
 #ifndef PTSS_ABLATE
 #define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
 #endif
 #ifndef PTSS_WAVE_COMPACT
 #define PTSS_WAVE_COMPACT 1   // 1: per-wave compaction, no barriers; 0: per-workgroup (LDS + 2 barriers)
+#endif
+#ifndef PTSS_TRI_GUARD2
+#define PTSS_TRI_GUARD2 0
 #endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16

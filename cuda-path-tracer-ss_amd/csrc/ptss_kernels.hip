@@ -144,11 +144,17 @@ struct TriRows {  // one staged triangle: {v0, bits(materialIdx)}, {e1, 0}, {e2,
 };
 __device__ __forceinline__ TriRows loadTri(const float4* tr) { return TriRows{tr[0], tr[1], tr[2]}; }
 
+#if PTSS_TRI_GUARD2  // A/B: the general reciprocal (two range compares)
+__device__ __forceinline__ float triRcp(float det) { return ptm::rcp(det); }
+#else
+__device__ __forceinline__ float triRcp(float det) { return ptm::rcp_if_above_1em7(det); }
+#endif
+
 __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d, float limit, bool live) {
     const vec3 v0 = xyz(tr.a), e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
-    const float inverseDet = ptm::rcp(det);  // 1 / det, Primitives.h:44
+    const float inverseDet = triRcp(det);  // 1 / det, Primitives.h:44; unused when |det| <= 1e-7
     const vec3 s = o - v0;
     const vec3 r = cross(s, e1);
     const float dist = dot(e2, r) * inverseDet;
@@ -206,7 +212,7 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
     const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
-    const float inverseDet = ptm::rcp(det);  // 1 / det, Primitives.h:44
+    const float inverseDet = triRcp(det);  // 1 / det, Primitives.h:44; unused when |det| <= 1e-7
     const float dist = ps.w * inverseDet;
     const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
     TriHit h;

@@ -12,7 +12,10 @@ spec.loader.exec_module(b)
 VARIANTS = {
     "w1": ["PTSS_MINWAVES=1"],
     "w4": ["PTSS_MINWAVES=4"],
+    "w5": ["PTSS_MINWAVES=5"],
     "w6": ["PTSS_MINWAVES=6"],
+    "w7": ["PTSS_MINWAVES=7"],
+    "w8": ["PTSS_MINWAVES=8"],
     "b128": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
     "b512": ["PTSS_BLOCK=512"],
     "s8": ["PTSS_SHARDS=8"],
@@ -29,6 +32,7 @@ VARIANTS = {
     "a3": ["PTSS_ABLATE=3"],
     "a7": ["PTSS_ABLATE=7"],
     "a15": ["PTSS_ABLATE=15"],
+    "g2": ["PTSS_TRI_GUARD2=1"],  # triangle reciprocal with both range compares
 }
 
 if __name__ == "__main__":
