@@ -34,8 +34,9 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_BLOCK 256
 #endif
 #ifndef PTSS_MINWAVES
-#define PTSS_MINWAVES 6   // __launch_bounds__ waves/SIMD: caps the bounce kernel at 80 VGPRs. With the vectorisers off (build.py)
-                          // that fits with at most 8 B of scratch: +6 % over 5 waves / 96 VGPRs; 7 waves (72) spills and loses 1 %
+#define PTSS_MINWAVES 7   // __launch_bounds__ waves/SIMD: caps the bounce kernel at 72 VGPRs. With the vectorisers off (build.py) and
+                          // PTSS_DEFER_LOADS the only scratch left is in a cold IEEE-division escape block. Measured, same box:
+                          // 5 waves (96 VGPRs) 13.3, 6 (80) 14.2, 7 (72) 14.5, 8 (64, spills) 11.4 Grays/s
 #endif
 #ifndef PTSS_ABLATE
 #define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
@@ -45,6 +46,11 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #endif
 #ifndef PTSS_TRI_GUARD2
 #define PTSS_TRI_GUARD2 0
+#endif
+// 1: a ray's planes are fetched where the tile first needs them (origin/direction, then RNG, then radiance/throughput/
+// pixel) instead of all at the top: 13 fewer live registers across the closest-hit loops
+#ifndef PTSS_DEFER_LOADS
+#define PTSS_DEFER_LOADS 1
 #endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16

@@ -65,19 +65,31 @@ struct RayRegs {
     bool active;
 };
 
-__device__ __forceinline__ void loadRay(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
+// PTSS_DEFER_LOADS fetches a ray's planes in the order the tile needs them, so that no plane occupies registers before
+// its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
+// throughput / pixel for the update at the end.
+__device__ __forceinline__ void loadRayGeometry(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
     r.o = vec3{pool[kOx * cap + i], pool[kOy * cap + i], pool[kOz * cap + i]};
     r.d = vec3{pool[kDx * cap + i], pool[kDy * cap + i], pool[kDz * cap + i]};
-    r.L0 = vec3{pool[kL0x * cap + i], pool[kL0y * cap + i], pool[kL0z * cap + i]};
-    r.T = vec3{pool[kTx * cap + i], pool[kTy * cap + i], pool[kTz * cap + i]};
-    r.pix = asU(pool[kPix * cap + i]);
+    r.active = true;
+}
+__device__ __forceinline__ void loadRayRng(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
     r.rng.v[0] = asU(pool[kR0 * cap + i]);
     r.rng.v[1] = asU(pool[kR1 * cap + i]);
     r.rng.v[2] = asU(pool[kR2 * cap + i]);
     r.rng.v[3] = asU(pool[kR3 * cap + i]);
     r.rng.v[4] = asU(pool[kR4 * cap + i]);
     r.rng.d = asU(pool[kRd * cap + i]);
-    r.active = true;
+}
+__device__ __forceinline__ void loadRayRadiance(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
+    r.L0 = vec3{pool[kL0x * cap + i], pool[kL0y * cap + i], pool[kL0z * cap + i]};
+    r.T = vec3{pool[kTx * cap + i], pool[kTy * cap + i], pool[kTz * cap + i]};
+    r.pix = asU(pool[kPix * cap + i]);
+}
+__device__ __forceinline__ void loadRay(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
+    loadRayGeometry(pool, cap, i, r);
+    loadRayRng(pool, cap, i, r);
+    loadRayRadiance(pool, cap, i, r);
 }
 
 __device__ __forceinline__ void storeRay(float* __restrict__ pool, uint32_t cap, uint32_t i, const RayRegs& r) {
@@ -699,7 +711,11 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 ray.active = true;
             }
         } else {
+#if PTSS_DEFER_LOADS
+            if (valid) loadRayGeometry(in, cap, i, ray);
+#else
             if (valid) loadRay(in, cap, i, ray);
+#endif
         }
         PTSS_STAMP(0);  // ray load / eye-ray generation
 #if PTSS_ABLATE & 2
@@ -711,10 +727,14 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
 #endif
         PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
+#if PTSS_DEFER_LOADS
+        if constexpr (!kFirst) {
+            if (valid) loadRayRng(in, cap, i, ray);
+        }
+#endif
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
         float cosI = 0;
         int materialIdx = 0;
-        vec3 directRadiance = v3(0, 0, 0);
         if (hit) {
             point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
             if (h.kind == 1) {
@@ -726,7 +746,6 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 materialIdx = (int)asU(sc[L.offTri + 3 * h.idx].w);
             }
             cosI = dot(-ray.d, normal);
-            directRadiance = v3(0, 0, 0) + xyz(sc[L.offMaterial + 5 * materialIdx + 3]);  // emmitance, :163
         }
         const bool inside = cosI <= 0.0f;
         const bool lit = hit && !inside && !(PTSS_ABLATE & 1);  // shade() runs, :166-169
@@ -822,8 +841,15 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
 
         // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
         bool alive = false;
+#if PTSS_DEFER_LOADS
+        if constexpr (!kFirst) {
+            if (valid) loadRayRadiance(in, cap, i, ray);
+        }
+#endif
         if (valid) {
             if (hit) {
+                // emmitance, :163 — read here, after the shadow passes, instead of being held in registers across them
+                vec3 directRadiance = v3(0, 0, 0) + xyz(mat[3]);
                 if (lit) directRadiance = directRadiance + radiance;
                 vec3 indirectRadiance = v3(1, 1, 1);
                 if (!kLast && !(PTSS_ABLATE & 4)) indirectRadiance = scatter(mat, ray, point, normal, cosI);

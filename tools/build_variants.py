@@ -16,6 +16,9 @@ VARIANTS = {
     "w6": ["PTSS_MINWAVES=6"],
     "w7": ["PTSS_MINWAVES=7"],
     "w8": ["PTSS_MINWAVES=8"],
+    "w6d": ["PTSS_MINWAVES=6", "PTSS_DEFER_LOADS=1"],
+    "w7d": ["PTSS_MINWAVES=7", "PTSS_DEFER_LOADS=1"],
+    "w8d": ["PTSS_MINWAVES=8", "PTSS_DEFER_LOADS=1"],
     "b128": ["PTSS_BLOCK=128", "PTSS_SHARDS=32"],
     "b512": ["PTSS_BLOCK=512"],
     "s8": ["PTSS_SHARDS=8"],
