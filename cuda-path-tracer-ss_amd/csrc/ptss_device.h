@@ -52,6 +52,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #ifndef PTSS_DEFER_LOADS
 #define PTSS_DEFER_LOADS 1
 #endif
+// 1: a pass over fewer than 64 queued shadow segments gives each segment 2, 4 or 8 lanes that share the primitive list
+#ifndef PTSS_SPLIT_SPARSE
+#define PTSS_SPLIT_SPARSE 1
+#endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
 #endif

@@ -332,6 +332,47 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
     return occluded;
 }
 
+// ---- the same any-hit with the primitive list SPLIT over g = 1 << shift lanes per segment: lane `sub` of a
+// segment's group visits primitives sub, sub + g, sub + 2g, ...; the caller ORs the group's verdicts. Every test is
+// the scalar test on the same operands, and lineOfSight's answer is an OR over independent tests, so the verdict is
+// the one anyHit gives. Used when a pass over the wave's queue holds fewer than 64 segments: 8 segments x 8 lanes
+// cost an eighth of a dense pass instead of a whole one. Rows are gathered per lane here (no broadcast). ------------
+__device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance,
+                                            bool live, int shift, int sub) {
+    bool occluded = false;
+    const int g = 1 << shift;
+    const int sphereSteps = (L.numSpheres + g - 1) >> shift;
+    for (int base = 0; base < sphereSteps; base += 32) {
+        const int cnt = (sphereSteps - base < 32) ? (sphereSteps - base) : 32;
+        uint32_t mask = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const int idx = ((base + j) << shift) + sub;
+            const bool in = idx < L.numSpheres;
+            if (in && sphereMayHit(sc[L.offSphere + (in ? idx : 0)], lo, w_i)) mask |= 1u << j;
+        }
+        if (!live || occluded) mask = 0;
+        while (mask != 0) {
+            const int j = __builtin_ctz(mask);
+            mask &= mask - 1;
+            float t;
+            if (sphereTest(sc[L.offSphere + ((base + j) << shift) + sub], lo, w_i, distance, t)) {
+                occluded = true;
+                mask = 0;
+            }
+        }
+    }
+    const int triSteps = (L.numTriangles + g - 1) >> shift;
+    for (int k = 0; k < triSteps; ++k) {
+        if (!__any(live && !occluded)) break;
+        const int idx = (k << shift) + sub;
+        const bool in = idx < L.numTriangles;
+        const TriRows tcur = loadTri(sc + L.offTri + 3 * (in ? idx : 0));
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, live && in && !occluded);
+        occluded = occluded || th.hit;
+    }
+    return occluded;
+}
+
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
 __device__ __forceinline__ void addLambertTerm(vec3& radiance, float cosI, vec3 power, float distance2,
                                                float4 diffuse /* colour, diffAvg */) {
@@ -811,7 +852,37 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 queued += (uint32_t)__popcll(m);
             }
             waveLdsFence();
+#ifdef PTSS_QHIST  // diagnostic: histogram of the wave's queue length per NEE round (tools/queue_hist.py)
+            if (lane == 0) atomicAdd(&fb.stamps[queued == 0 ? 0 : (queued <= 8 ? 1 : (queued <= 16 ? 2 : (queued <= 32 ? 3 : (queued <= 64 ? 4 : (queued <= 72 ? 5 : (queued <= 96 ? 6 : 7))))))], 1ull);
+#endif
             PTSS_STAMP(2);  // surfel + light sampling + enqueue
+#if PTSS_SPLIT_SPARSE
+            // Passes over the wave's queue, each sized by what is left (wave-uniform): 49+ segments -> a dense pass,
+            // one lane per segment (anyHit, broadcast rows); fewer -> a chunk of 32 / 16 / 8 segments with 2 / 4 / 8
+            // lanes per segment sharing the primitive list (anyHitSplit), so that a pass costs about what it holds:
+            // 77 segments = 1 + 1/4 dense passes instead of 2, 13 segments = 1/4 instead of 1.
+            for (uint32_t e0 = 0; e0 < queued;) {
+                const uint32_t rem = queued - e0;
+                const uint32_t units = (rem + 7u) >> 3;  // of 8 segments
+                const int chunkLog = units >= 7u ? 6 : (units >= 4u ? 5 : (units >= 2u ? 4 : 3));
+                const int shift = 6 - chunkLog;                      // lanes per segment = 1 << shift
+                const uint32_t mine = lane >> shift;                 // this lane's segment within the chunk
+                const uint32_t sub = lane & ((1u << shift) - 1u);    // its share of the primitive list
+                const bool have = mine < rem;
+                const uint32_t es = have ? e0 + mine : 0u;
+                const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
+                const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
+                const float reach = wq[6 * kQueueCap + es];
+                const bool occ = (shift == 0) ? anyHit(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+                const unsigned long long verdicts = __ballot(occ);  // all lanes vote before anyone branches
+                const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
+                if (have && sub == 0u && (verdicts & group) != 0ull) {
+                    const uint32_t ow = wqOwner[es];
+                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
+                }
+                e0 += 1u << chunkLog;
+            }
+#else
             for (uint32_t e0 = 0; e0 < queued; e0 += 64) {  // dense passes over the wave's queue
                 const uint32_t e = e0 + lane;
                 const bool have = e < queued;
@@ -824,6 +895,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                     wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
                 }
             }
+#endif
             waveLdsFence();
             PTSS_STAMP(3);  // dense shadow passes
 #pragma unroll

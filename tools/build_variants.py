@@ -24,6 +24,8 @@ VARIANTS = {
     "s8": ["PTSS_SHARDS=8"],
     "s32": ["PTSS_SHARDS=32"],
     "stamps": ["PTSS_STAMPS=1"],
+    "qhist": ["PTSS_QHIST=1"],
+    "nosplit": ["PTSS_SPLIT_SPARSE=0"],
     "blockc": ["PTSS_WAVE_COMPACT=0"],
     "wc_s32": ["PTSS_SHARDS=32"],
     "wc_s64": ["PTSS_SHARDS=64"],
