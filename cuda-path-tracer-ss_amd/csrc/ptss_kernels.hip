@@ -388,15 +388,16 @@ __device__ __forceinline__ quat rotateVectorToVector(vec3 source, vec3 target) {
     return normalize(q4(1.0f + dot(source, target), axis.x, axis.y, axis.z));
 }
 
-// shared tail of the Lambert / Phong samplers, CudaTracer.cu:536-544, 550-558
-__device__ __forceinline__ vec3 lobeSample(vec3 axis, float theta, float y) {
-    const float r = ptm::sqrt(1 - y * y);
-    float sn, cs;
-    ptm::sincos(theta, sn, cs);
-    return rotate(rotateVectorToVector(v3(0, 1, 0), axis), v3(r * cs, y, r * sn));
-}
-
 // ---- computeIndirectRadianceAndScatter, CudaTracer.cu:208-318 ---------------------------------
+// The three random-direction samplers of the reference (Lambert :533-545, Phong :547-559, Beckmann :561-577) all
+// draw two uniforms and end the same way: a vector (a*cos(az), y, a*sin(az)) about +Y, rotated onto the lobe axis by
+// rotateVectorToVector (:579-585). With 64 incoherent rays nearly every wave holds lanes of all three kinds, so the
+// lobe CHOICE runs divergently (it is cheap) and the draws + sincos + rotation run ONCE, for all sampling lanes
+// together; each lane performs exactly the operations, in the order, that its own sampler performs in the
+// reference (the draws keep their order: Lambert/Phong use the first for the azimuth and the second for the
+// elevation, Beckmann the first for the elevation and the second for the azimuth).
+enum LobeKind { kLobeNone = 0, kLobeLambert = 1, kLobePhong = 2, kLobeBeckmann = 3 };
+
 __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 point, vec3 normal, float cosI) {
     const float4 mDiffuse = mat[0];   // diffuseColor, diffAvg
     const float4 mSpecular = mat[1];  // specularColor, specAvg
@@ -406,99 +407,122 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
 
     float r = ptrng::uniform(ray.rng);
 
+    int kind = kLobeNone;
+    bool decided = false;
+    vec3 axis = normal;
+    vec3 result = v3(0, 0, 0);
+    const vec3 incident = ray.d;
+
     if (mDiffuse.w > 0.0f) {
         r -= mDiffuse.w;
-        if (r < 0.0f) {
+        if (r < 0.0f) {  // randomDirectionLambert about the normal
             ray.o = point + ptm::kRayBump * normal;
-            const float theta = ptrng::uniform(ray.rng) * 2 * ptm::kPi;
-            const float s = ptrng::uniform(ray.rng);
-            ray.d = lobeSample(normal, theta, ptm::sqrt(s));  // randomDirectionLambert :533-545
-            return xyz(mDiffuse);
+            kind = kLobeLambert;
+            decided = true;
+            result = xyz(mDiffuse);
         }
     }
 
-    // computeSinT2AndRefractiveIndexes :474-494 (flips cosI when inside)
-    float n1, n2;
-    if (cosI > 0) {
-        n2 = mMisc.y;
-        n1 = 1.0f;
-    } else {
-        cosI = -cosI;
-        n1 = mMisc.y;
-        n2 = 1.0f;
-    }
-    const float n = ptm::div(n1, n2);
-    const float sinT2 = n * n * (1.0f - cosI * cosI);
-
-    // computeFresnelForReflectance :457-472
-    float fresnelReflective = 1.0f;
-    if (!(sinT2 > 1.0f)) {
-        const float cosT = ptm::sqrt(1.0f - sinT2);
-        const float r_s = ptm::div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
-        const float r_p = ptm::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
-        fresnelReflective = (r_s * r_s + r_p * r_p) * 0.5f;
-    }
-
-    if (mSpecular.w > 0.0f) {
-        if (flags & PTSS_MAT_FLAG_PURE_REFLECTION)
-            r -= mSpecular.w;
-        else
-            r -= mSpecular.w * fresnelReflective;
-
-        if (r < 0.0f) {
-            if (flags & PTSS_MAT_FLAG_COOK_TORRANCE) {
-                // randomDirectionBeckmann :561-577
-                const float roughness = mat[3].w;
-                const float theta = ptm::atan(-roughness * roughness * ptm::log(1.0f - ptrng::uniform(ray.rng)));
-                const float phi = ptrng::uniform(ray.rng) * 2 * ptm::kPi;
-                float sinPhi, cosPhi, sinTheta, cosTheta;
-                ptm::sincos(phi, sinPhi, cosPhi);
-                ptm::sincos(theta, sinTheta, cosTheta);
-                const vec3 m = v3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi);
-                const vec3 beckmannNormal = rotate(rotateVectorToVector(v3(0, 1, 0), normal), m);
-
-                const vec3 incident = ray.d;
-                // reflRay(ray, point, normal) :505-514
-                const float cosB = ptm::abs(dot(ray.d, beckmannNormal));
-                ray.d = ray.d - (2 * (-cosB)) * beckmannNormal;
-                ray.o = point + (beckmannNormal * ptm::kRayBump);
-
-                const vec3 half = normalize(ray.d - incident);
-                const float nh = ptm::abs(dot(normal, half));
-                const float nl = ptm::abs(dot(normal, ray.d));
-                const float vh = ptm::abs(dot(incident, half));
-                const float nv = ptm::abs(cosI);
-                const float geometric = ptm::min(ptm::min(1.0f, ptm::div(2 * nh * nl, vh)), ptm::div(2 * nh * nv, vh));
-                return xyz(mSpecular) * geometric / nv;
-            }
-            // reflRay(ray, surfel, cosI) :496-503
-            ray.d = ray.d - (2 * (-cosI)) * normal;
-            ray.o = point + (normal * ptm::kRayBump);
-            if (mMisc.x != ptm::inf()) {  // randomDirectionPhong :547-559
-                const float theta = ptrng::uniform(ray.rng) * 2 * ptm::kPi;
-                const float s = ptrng::uniform(ray.rng);
-                ray.d = lobeSample(ray.d, theta, ptm::pow(s, ptm::rcp(mMisc.x + 1)));
-            }
-            return xyz(mSpecular);
+    if (!decided) {
+        // computeSinT2AndRefractiveIndexes :474-494 (flips cosI when inside)
+        float n1, n2;
+        if (cosI > 0) {
+            n2 = mMisc.y;
+            n1 = 1.0f;
+        } else {
+            cosI = -cosI;
+            n1 = mMisc.y;
+            n2 = 1.0f;
         }
-    }
+        const float n = ptm::div(n1, n2);
+        const float sinT2 = n * n * (1.0f - cosI * cosI);
 
-    if (refrAvg > 0.0f) {
-        const float fresnelRefractive = 1.0f - fresnelReflective;
-        r -= refrAvg * fresnelRefractive;
-        if (r < 0.0f) {
-            // refrRay :516-531
-            if (sinT2 > 1.0f) ray.active = false;
+        // computeFresnelForReflectance :457-472
+        float fresnelReflective = 1.0f;
+        if (!(sinT2 > 1.0f)) {
             const float cosT = ptm::sqrt(1.0f - sinT2);
-            const vec3 w_o = normalize(n * ray.d + (n * cosI - cosT) * normal);
-            ray.o = point + (w_o * ptm::kRayBump);
-            ray.d = w_o;
-            return v3(1, 1, 1);
+            const float r_s = ptm::div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
+            const float r_p = ptm::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
+            fresnelReflective = (r_s * r_s + r_p * r_p) * 0.5f;
         }
+
+        if (mSpecular.w > 0.0f) {
+            if (flags & PTSS_MAT_FLAG_PURE_REFLECTION)
+                r -= mSpecular.w;
+            else
+                r -= mSpecular.w * fresnelReflective;
+
+            if (r < 0.0f) {
+                decided = true;
+                if (flags & PTSS_MAT_FLAG_COOK_TORRANCE) {
+                    kind = kLobeBeckmann;  // micro-normal about the surface normal; the reflection follows below
+                } else {
+                    // reflRay(ray, surfel, cosI) :496-503
+                    ray.d = ray.d - (2 * (-cosI)) * normal;
+                    ray.o = point + (normal * ptm::kRayBump);
+                    if (mMisc.x != ptm::inf()) {  // randomDirectionPhong about the mirror direction
+                        kind = kLobePhong;
+                        axis = ray.d;
+                    }
+                    result = xyz(mSpecular);
+                }
+            }
+        }
+
+        if (!decided && refrAvg > 0.0f) {
+            const float fresnelRefractive = 1.0f - fresnelReflective;
+            r -= refrAvg * fresnelRefractive;
+            if (r < 0.0f) {
+                // refrRay :516-531
+                decided = true;
+                if (sinT2 > 1.0f) ray.active = false;
+                const float cosT = ptm::sqrt(1.0f - sinT2);
+                const vec3 w_o = normalize(n * ray.d + (n * cosI - cosT) * normal);
+                ray.o = point + (w_o * ptm::kRayBump);
+                ray.d = w_o;
+                result = v3(1, 1, 1);
+            }
+        }
+
+        if (!decided) ray.active = false;  // absorbed, :316-317
     }
 
-    ray.active = false;
-    return v3(0, 0, 0);
+    if (kind != kLobeNone) {  // one copy of the sampler for every kind
+        const float u1 = ptrng::uniform(ray.rng);
+        const float u2 = ptrng::uniform(ray.rng);
+        float azimuth, a, y;
+        if (kind == kLobeBeckmann) {
+            const float roughness = mat[3].w;
+            const float theta = ptm::atan(-roughness * roughness * ptm::log(1.0f - u1));  // :564
+            azimuth = u2 * 2 * ptm::kPi;                                                      // :565
+            ptm::sincos(theta, a, y);  // m = (sinTheta * cosPhi, cosTheta, sinTheta * sinPhi), :567-569
+        } else {
+            azimuth = u1 * 2 * ptm::kPi;                                                      // :536, :550
+            y = (kind == kLobeLambert) ? ptm::sqrt(u2) : ptm::pow(u2, ptm::rcp(mMisc.x + 1));  // :537-538, :551-552
+            a = ptm::sqrt(1 - y * y);                                                          // :539, :553
+        }
+        float sn, cs;
+        ptm::sincos(azimuth, sn, cs);
+        const vec3 sampled = rotate(rotateVectorToVector(v3(0, 1, 0), axis), v3(a * cs, y, a * sn));
+        if (kind == kLobeBeckmann) {
+            const vec3 beckmannNormal = sampled;
+            // reflRay(ray, point, normal) :505-514
+            const float cosB = ptm::abs(dot(ray.d, beckmannNormal));
+            ray.d = ray.d - (2 * (-cosB)) * beckmannNormal;
+            ray.o = point + (beckmannNormal * ptm::kRayBump);
+
+            const vec3 half = normalize(ray.d - incident);
+            const float nh = ptm::abs(dot(normal, half));
+            const float nl = ptm::abs(dot(normal, ray.d));
+            const float vh = ptm::abs(dot(incident, half));
+            const float nv = ptm::abs(cosI);
+            const float geometric = ptm::min(ptm::min(1.0f, ptm::div(2 * nh * nl, vh)), ptm::div(2 * nh * nv, vh));
+            result = xyz(mSpecular) * geometric / nv;
+        } else {
+            ray.d = sampled;
+        }
+    }
+    return result;
 }
 
 // one channel of writeToPixelsKernel, CudaTracer.cu:72-85
