@@ -57,6 +57,7 @@ struct ptss_context {
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
     float* dFsum = nullptr;
+    uint32_t* dStaged = nullptr;  // S > 1: per-stream sample words of the current pass
     uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
     uint32_t poolStride = 0, regionCap = 0;  // ray pools: kShards regions of regionCap slots
     uint32_t samples = 1;                    // cfg.samplesPerPass (sample lanes per pixel)
@@ -186,6 +187,7 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.stamps = c->dTotal + 1;
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
+    fb.staged = c->dStaged;
     fb.pixels = pixels;
     fb.capacity = c->poolStride;
     fb.regionCap = c->regionCap;
@@ -363,6 +365,10 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(hipMalloc(&c->dFsum, (size_t)3 * c->capacity * c->samples * sizeof(float)));
         CREATE_TRY(hipMemset(c->dFsum, 0, (size_t)3 * c->capacity * c->samples * sizeof(float)));
     }
+    if (c->samples > 1) {
+        CREATE_TRY(hipMalloc(&c->dStaged, (size_t)c->capacity * c->samples * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(c->dStaged, 0, (size_t)c->capacity * c->samples * sizeof(uint32_t)));
+    }
     CREATE_TRY(hipEventCreate(&c->evStart));
     CREATE_TRY(hipEventCreate(&c->evStop));
 
@@ -423,6 +429,7 @@ int ptss_destroy(ptss_context* c) {
     (void)hipFree(c->dTotal);
     (void)hipFree(c->dAccumOwned);
     (void)hipFree(c->dFsum);
+    (void)hipFree(c->dStaged);
     delete c;
     return PTSS_OK;
 }
@@ -518,7 +525,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         }
     }
     HIP_TRY(ptss::launchFlush(st, fb, numIterations));  // :637
-    if (c->samples > 1 && pixels) HIP_TRY(ptss::launchDisplay(st, fb));  // display value once all S samples are in
+    if (c->samples > 1) HIP_TRY(ptss::launchDisplay(st, fb));  // S > 1: add the pass's staged samples, then the display value
 
     // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
     if (!c->haveHint || (c->frameIndex & 7u) == 0) {

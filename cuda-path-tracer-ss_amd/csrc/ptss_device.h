@@ -110,6 +110,7 @@ struct FrameBuffers {
     unsigned long long* stamps;   // [8] wave-cycles per phase, written only by -DPTSS_STAMPS diagnostic builds
     uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
     float* fsum;             // float3 per local pixel or nullptr
+    uint32_t* staged;        // S > 1 only: this pass's sample of every stream, x | y << 8 | z << 16 (one plane per sample lane)
     ptss_uchar4* pixels;     // display buffer or nullptr
     uint32_t capacity;       // pool plane stride = kShards * regionCap
     uint32_t regionCap;      // slots per shard region

@@ -36,6 +36,9 @@ VARIANTS = {
     "a2": ["PTSS_ABLATE=2"],
     "a3": ["PTSS_ABLATE=3"],
     "a7": ["PTSS_ABLATE=7"],
+    "a8": ["PTSS_ABLATE=8"],   # no finishPath (tone map, accumulate, park RNG)
+    "a64": ["PTSS_ABLATE=64"],    # finishPath without the accumulator atomics (S > 1)
+    "a128": ["PTSS_ABLATE=128"],  # finishPath without parking the RNG state
     "a15": ["PTSS_ABLATE=15"],
     "g2": ["PTSS_TRI_GUARD2=1"],  # triangle reciprocal with both range compares
 }
