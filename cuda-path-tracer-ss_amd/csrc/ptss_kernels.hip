@@ -551,9 +551,10 @@ struct U3 {  // one totalPixelColors entry, moved as a single 12-byte access
 };
 
 // A path ended: writeToPixelsKernel for this ray (CudaTracer.cu:63-104) + park the RNG stream.
-// With S > 1 sample lanes several lanes of a launch may end paths of the SAME pixel: the integer sums then
-// go through atomics (order-free, still exact), the display value is written by displayKernel once the
-// pass is complete, and the float sum is kept per stream (one writer each; summed in lane order on read).
+// S == 1: the reference's read-modify-write of totalPixelColors and the display pixel, right here (one writer per pixel).
+// S > 1: several lanes of a launch may end paths of the SAME pixel, so the tone-mapped 8-bit sample is parked in the
+// stream's own word instead and displayKernel adds the S words of each pixel into the accumulator when the pass is
+// complete (integer sums: order-free, still exact); the float sum is kept per stream (summed in lane order on read).
 __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs& r) {
     const uint32_t p = pixOf(r.pix), lane = laneOf(r.pix);
     const uint32_t stream = lane * fb.plane + p;
