@@ -15,6 +15,7 @@
 
 #include "ptss.h"
 #include "ptss_device.h"
+#include "ptquant.h"
 
 using namespace ptv;
 
@@ -108,6 +109,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offMaterial = off;    off += 5 * L.numMaterials;
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
+    L.offQuant = off;       off += ptq::kTableFloats / 4;
     L.offPrimSphere = off;  off += L.numSpheres;
     L.offPrimTri = off;     off += 2 * L.numTriangles;
     L.totalVec4 = off;
@@ -120,6 +122,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     for (size_t i = 0; i < s.numAreaLights; ++i)
         if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
+    ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));
     for (int i = 0; i < L.numSpheres; ++i) {
         const ptss_sphere& sp = s.spheres[i];
         // radius*radius is the same single rounding the reference performs per test (Primitives.h:113)
@@ -188,6 +191,7 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
     fb.staged = c->dStaged;
+    fb.quantTable = reinterpret_cast<const float*>(c->dScene + c->layout.offQuant);
     fb.pixels = pixels;
     fb.capacity = c->poolStride;
     fb.regionCap = c->regionCap;

@@ -56,6 +56,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #ifndef PTSS_SPLIT_SPARSE
 #define PTSS_SPLIT_SPARSE 1
 #endif
+// 1: 8-bit tone mapping through the threshold table (ptquant.h); 0: the literal clamp/pow/scale sequence
+#ifndef PTSS_QUANT_TABLE
+#define PTSS_QUANT_TABLE 1
+#endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
 #endif
@@ -81,6 +85,7 @@ struct SceneLayout {
                         //        {emmitance, roughness},{specularExponent, indexOfRefraction, bits(flags), 0}
     int offPointLight;  // P x 2: {position,0},{power,0}
     int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
+    int offQuant;       // 65 rows: the 8-bit tone-map thresholds T[0..256] (ptquant.h), read by finishPath
     int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
     int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}
     int totalVec4;
@@ -110,6 +115,7 @@ struct FrameBuffers {
     unsigned long long* stamps;   // [8] wave-cycles per phase, written only by -DPTSS_STAMPS diagnostic builds
     uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
     float* fsum;             // float3 per local pixel or nullptr
+    const float* quantTable; // the same thresholds in global memory (flushKernel has no staged scene)
     uint32_t* staged;        // S > 1 only: this pass's sample of every stream, x | y << 8 | z << 16 (one plane per sample lane)
     ptss_uchar4* pixels;     // display buffer or nullptr
     uint32_t capacity;       // pool plane stride = kShards * regionCap

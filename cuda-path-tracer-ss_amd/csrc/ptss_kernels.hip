@@ -24,6 +24,7 @@
 // Arithmetic mirrors oracle/oracle.cpp operation for operation (ptmath.h; -ffp-contract=off);
 // every restructuring below is argued exact where it is made.
 #include "ptss_device.h"
+#include "ptquant.h"
 
 using namespace ptv;
 
@@ -525,12 +526,15 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
     return result;
 }
 
-// one channel of writeToPixelsKernel, CudaTracer.cu:72-85
-__device__ __forceinline__ uint32_t quantizeSample(float radiance) {
-    float v = ptm::clamp(radiance, 0.0f, 1.0f);
-    v = ptm::pow(v, ptm::kGamma);
-    v = ptm::clamp(255 * v + 0.5f, 0.f, 255.f);
-    return (v == v) ? (uint32_t)v : 0u;
+// one channel of writeToPixelsKernel, CudaTracer.cu:72-85: clamp, gamma 1/2.2, scale to 8 bits. PTSS_QUANT_TABLE = 1
+// takes the proven-equal table form (ptquant.h): a hardware log2/exp2 guess settled by two exact threshold compares,
+// ~12 instructions instead of the ~90 of the software pow — three of these run for every wave that ends a path.
+__device__ __forceinline__ uint32_t quantizeSample(float radiance, const float* T) {
+#if PTSS_QUANT_TABLE
+    return ptq::quantize_fast(radiance, T);
+#else
+    return ptq::quantize_literal(radiance);
+#endif
 }
 
 // The per-pixel home record of the random stream: 8 words (v0..v4, d, 2 pad) = one 32-byte sector, so
@@ -555,10 +559,10 @@ struct U3 {  // one totalPixelColors entry, moved as a single 12-byte access
 // S > 1: several lanes of a launch may end paths of the SAME pixel, so the tone-mapped 8-bit sample is parked in the
 // stream's own word instead and displayKernel adds the S words of each pixel into the accumulator when the pass is
 // complete (integer sums: order-free, still exact); the float sum is kept per stream (summed in lane order on read).
-__device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs& r) {
+__device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs& r, const float* quantT) {
     const uint32_t p = pixOf(r.pix), lane = laneOf(r.pix);
     const uint32_t stream = lane * fb.plane + p;
-    const uint32_t qx = quantizeSample(r.L0.x), qy = quantizeSample(r.L0.y), qz = quantizeSample(r.L0.z);
+    const uint32_t qx = quantizeSample(r.L0.x, quantT), qy = quantizeSample(r.L0.y, quantT), qz = quantizeSample(r.L0.z, quantT);
     if (fb.samples == 1) {
         U3* acc = reinterpret_cast<U3*>(fb.accum) + p;
         U3 t = *acc;
@@ -742,6 +746,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
     } else {
         sc = sceneBlob;
     }
+    const float* quantT = reinterpret_cast<const float*>(sc + L.offQuant);
 
     const uint32_t cap = fb.capacity;
     const float* __restrict__ in = fb.pool[bounce & 1] + shard * fb.regionCap;  // this shard's region
@@ -992,18 +997,18 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 if ((int)lane == leader)
                     base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], (uint32_t)__popcll(live));
                 slot = base0;  // consumed after the finish work below
-                if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+                if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
                 slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
                 if (alive) storeRay(out, cap, slot, ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
-                finishPath(fb, ray);
+                finishPath(fb, ray, quantT);
             }
         } else {
-            if (valid && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+            if (valid && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
         }
         PTSS_STAMP(5);
 #else
-        if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray);
+        if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
         PTSS_STAMP(5);  // finish (tone map, accumulate, park RNG)
         if constexpr (!kLast) {
             const unsigned long long live = __ballot(alive);
@@ -1060,7 +1065,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
                 (void)ptrng::uniform(ray.rng);
                 ray.L0 = v3(0, 0, 0);
                 ray.pix = i | (l << 28);
-                finishPath(fb, ray);
+                finishPath(fb, ray, fb.quantTable);
             }
     } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
         for (int s = 0; s < kShards; ++s) {
@@ -1068,7 +1073,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
             if (i < n) {
                 RayRegs ray;
                 loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);
-                finishPath(fb, ray);
+                finishPath(fb, ray, fb.quantTable);
             }
         }
     }

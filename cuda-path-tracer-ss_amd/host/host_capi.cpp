@@ -8,6 +8,7 @@
 
 #include "HostOps.h"
 #include "Scene.h"
+#include "ptquant.h"
 #include "xorwow.h"
 
 struct ptss_scene {
@@ -84,6 +85,20 @@ int ptss_probe_math(int op, const float* x, const float* y, float* out, size_t n
             default: return PTSS_HOST_EINVAL;
         }
     }
+    return PTSS_HOST_OK;
+}
+
+int ptss_probe_quantize(const float* x, unsigned int* out, size_t n) {
+    if (!x || !out) return PTSS_HOST_EINVAL;
+    for (size_t i = 0; i < n; ++i) out[i] = ptq::quantize_literal(x[i]);
+    return PTSS_HOST_OK;
+}
+
+int ptss_probe_quant_table(float* out257) {
+    if (!out257) return PTSS_HOST_EINVAL;
+    float T[ptq::kTableFloats];
+    if (!ptq::build_thresholds(T)) return PTSS_HOST_EINVAL;
+    for (int k = 0; k <= 256; ++k) out257[k] = T[k];
     return PTSS_HOST_OK;
 }
 

@@ -42,6 +42,10 @@ int ptss_tile_rows(int height, int band_rows, int rank, int world, int* rows, in
 
 /* Probes (tests only). op: 0 sin, 1 cos, 2 tan, 3 atan, 4 log, 5 exp, 6 pow(x,y), 7 sqrt */
 int ptss_probe_math(int op, const float* x, const float* y, float* out, size_t n);
+/* 8-bit tone-mapped sample of a radiance value, literal (CudaTracer.cu:72-85), and the 257 thresholds T[0..256] of its
+ * table form (csrc/ptquant.h): T[k] = smallest float whose sample is >= k (T[0] = -inf, T[256] = NaN). Returns PTSS_HOST_EINVAL if not monotone. */
+int ptss_probe_quantize(const float* x, unsigned int* out, size_t n);
+int ptss_probe_quant_table(float* out257);
 /* XORWOW state after curand_init(seed, subsequence, 0): out6 = v0..v4, d. */
 int ptss_probe_rng_init(unsigned long long seed, unsigned int subsequence, unsigned int* out6);
 /* n raw draws and the matching (0,1] floats from a state; state advanced in place. */

@@ -7,6 +7,8 @@
 //               on every b-mantissa x 4096 a-mantissas for a grid of exponent pairs that straddles the guard range,
 //               plus zeros / infinities / NaNs. A control column counts how often the UNcorrected quotient a*r differs,
 //               to show the comparison is not vacuous.
+//   quantize  : the table form of the 8-bit tone map (csrc/ptquant.h) against the literal clamp/pow/scale sequence for every
+//               one of the 2^32 bit patterns; a control counts how often the hardware first guess alone is off.
 // NaN results must be NaN on both sides (payload ignored).
 // usage: ptss_mathcheck [div_chunks (0..32, default 32)]
 #include <hip/hip_runtime.h>
@@ -15,6 +17,7 @@
 #include <stdlib.h>
 
 #include "ptmath.h"
+#include "ptquant.h"
 
 __device__ __forceinline__ bool same(float a, float b) {
     if (a != a && b != b) return true;
@@ -30,6 +33,18 @@ __global__ void checkUnary(unsigned long long* bad, uint32_t* firstBad) {
             if (atomicAdd(&bad[0], 1ull) == 0) firstBad[0] = (uint32_t)b;
         if (!same(ptm::sqrt(x), __builtin_sqrtf(x)))
             if (atomicAdd(&bad[1], 1ull) == 0) firstBad[1] = (uint32_t)b;
+    }
+}
+
+__global__ void checkQuantize(unsigned long long* bad, const float* T) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = tid; b < (1ull << 32); b += stride) {
+        const float x = __builtin_bit_cast(float, (uint32_t)b);
+        const uint32_t want = ptq::quantize_literal(x);
+        if (ptq::quantize_fast(x, T) != want) atomicAdd(&bad[6], 1ull);
+        const float guess = __builtin_fmaf(255.0f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * ptm::kGamma), 0.5f);
+        if ((uint32_t)__builtin_amdgcn_fmed3f(guess, 0.0f, 255.0f) != want) atomicAdd(&bad[7], 1ull);  // control
     }
 }
 
@@ -96,6 +111,14 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(checkUnary, dim3(256 * 16), dim3(256), 0, 0, dBad, dFirst);
     if (hipDeviceSynchronize() != hipSuccess) return 3;
 
+    float hT[ptq::kTableFloats];
+    const bool monotone = ptq::build_thresholds(hT);
+    float* dT;
+    hipMalloc(&dT, sizeof(hT));
+    hipMemcpy(dT, hT, sizeof(hT), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(checkQuantize, dim3(256 * 16), dim3(256), 0, 0, dBad, dT);
+    if (hipDeviceSynchronize() != hipSuccess) return 3;
+
     const uint32_t per = (1u << 23) / 32;
     for (int c = 0; c < divChunks && c < 32; ++c) {
         hipLaunchKernelGGL(checkDivMantissas, dim3(per), dim3(256), 0, 0, dBad, (uint32_t)c * per, per);
@@ -130,5 +153,7 @@ int main(int argc, char** argv) {
     printf("div_mantissa_mismatch=%llu div_pairs_checked=%llu control_uncorrected_mismatch=%llu div_exponent_mismatch=%llu "
            "div_special_mismatch=%llu\n",
            bad[2], (unsigned long long)(divChunks > 32 ? 32 : divChunks) * per * (1ull << 23), bad[3], bad[4], bad[5]);
-    return (bad[0] || bad[1] || bad[2] || bad[4] || bad[5]) ? 1 : 0;
+    printf("quant_mismatch=%llu quant_checked=4294967296 quant_guess_alone_mismatch=%llu quant_table_monotone=%d\n", bad[6], bad[7],
+           monotone ? 1 : 0);
+    return (bad[0] || bad[1] || bad[2] || bad[4] || bad[5] || bad[6] || !monotone) ? 1 : 0;
 }

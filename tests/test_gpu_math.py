@@ -1,7 +1,8 @@
 """The device fast paths of ptm::rcp / ptm::sqrt / ptm::div (hardware approximation + one fma correction) are only
 legitimate because they equal the IEEE results bit for bit. That is proven here by exhaustion on the GPU under test:
 every one of the 2^32 float32 patterns for rcp and sqrt; every one of the 2^46 mantissa pairs for div (~45 s), plus
-the guarded function across an exponent grid and the special values."""
+the guarded function across an exponent grid and the special values. Likewise the table form of the 8-bit tone map
+(csrc/ptquant.h) against the literal clamp / pow / scale sequence, for every float32 pattern."""
 import os
 import re
 import subprocess
@@ -26,4 +27,8 @@ def test_fast_paths_are_ieee_by_exhaustion():
     assert int(d.group(1)) == 0 and int(d.group(4)) == 0 and int(d.group(5)) == 0, r.stdout
     assert int(d.group(2)) == int(chunks) * (2 ** 18) * (2 ** 23)
     assert int(d.group(3)) > 0, "control: the uncorrected quotient must differ somewhere, or the check is vacuous"
+    q = re.search(r"quant_mismatch=(\d+) quant_checked=(\d+) quant_guess_alone_mismatch=(\d+) quant_table_monotone=(\d)", r.stdout)
+    assert q, r.stdout
+    assert int(q.group(1)) == 0 and int(q.group(2)) == 2 ** 32 and q.group(4) == "1", r.stdout
+    assert int(q.group(3)) > 0, "control: the hardware guess alone must be off somewhere, or the check is vacuous"
     assert r.returncode == 0

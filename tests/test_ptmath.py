@@ -101,3 +101,31 @@ def test_tracer_constants():
     t = ev("tan", [np.float32(math.pi) / np.float32(2) * np.float32(0.5)])[0]
     assert abs(float(t) - 1.0) <= 1.2e-7
     assert ev("sqrt", [2.0])[0] == np.float32(math.sqrt(2.0))
+
+
+def test_tone_map_threshold_table_describes_the_literal_function():
+    """csrc/ptquant.h: T[k] is the smallest float whose 8-bit sample is >= k. Checked here on the host: the table is
+    strictly increasing, each threshold and its predecessor float sit on the two sides of a step, and resolving random
+    radiances through the table (searchsorted) reproduces the literal clamp / pow / scale function. The device form
+    (hardware guess + two compares) is proven against the literal one for all 2^32 patterns in tests/test_gpu_math.py."""
+    import ctypes as C
+    L = ptss.host_lib()
+    T = np.zeros(257, np.float32)
+    assert L.ptss_probe_quant_table(T.ctypes.data_as(_f32p)) == 0
+    assert T[0] == -np.inf and np.isnan(T[256]) and np.all(np.diff(T[1:256]) > 0) and 0 < T[1] and T[255] < 1
+
+    def literal(x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(x.size, np.uint32)
+        assert L.ptss_probe_quantize(x.ctypes.data_as(_f32p), out.ctypes.data_as(C.POINTER(C.c_uint)), x.size) == 0
+        return out
+
+    at = T[1:256]
+    below = np.nextafter(at, np.float32(-1), dtype=np.float32)
+    assert np.array_equal(literal(at), np.arange(1, 256)) and np.array_equal(literal(below), np.arange(0, 255))
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(200000, np.float32), rng.random(50000, np.float32) ** 8, np.float32([0, 1, -1, 2, np.inf, -np.inf, np.nan, 1e-30, 0.5])])
+    want = literal(x)
+    via_table = np.where(np.isnan(x), 0, np.searchsorted(T[1:256], x, side="right")).astype(np.uint32)
+    assert np.array_equal(via_table, want)
+    assert want[-3] == 0 and want[200000 + 50000 + 1] == 255 and want[200000 + 50000 + 6] == 0  # 1e-30, 1.0, NaN

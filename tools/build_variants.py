@@ -26,6 +26,7 @@ VARIANTS = {
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
     "nosplit": ["PTSS_SPLIT_SPARSE=0"],
+    "powq": ["PTSS_QUANT_TABLE=0"],  # literal clamp/pow/scale tone map
     "blockc": ["PTSS_WAVE_COMPACT=0"],
     "wc_s32": ["PTSS_SHARDS=32"],
     "wc_s64": ["PTSS_SHARDS=64"],
