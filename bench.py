@@ -7,8 +7,8 @@
 A "step" is one pass of the hot path = one call of the generateFrame drop-in (reference
 CudaTracer.cu:587-647): eye rays -> up to 8 x [intersect + NEE + scatter + compaction] -> accumulate,
 for S = --samples-per-pass independent samples per pixel (cfg.samplesPerPass; S = 1 is the reference's one
-sample per tick; the default S = 16 x 125 passes is the config's 2000 spp, and keeps every launch — and every
-shard of a multi-GPU run — wide enough to fill the chip; the image does not depend on N). Workload at every
+sample per tick; the default S = 40 x 50 passes is the config's 2000 spp, and keeps every launch — and every
+shard of an 8-GPU run — wide enough to fill the chip; the image does not depend on N). Workload at every
 N: BASELINE.json configs[2]/[3] — 1920x1080, scene preset "mixed" (22 spheres + 16 triangles, Lambert /
 Phong / Cook-Torrance / glass / mirror), 8 bounces. For N > 1 the
 SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
@@ -63,9 +63,9 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=125)
-    ap.add_argument("--samples-per-pass", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--samples-per-pass", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -191,8 +191,10 @@ def main():
             pmc = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_file):
-                try:
-                    pmc = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+                try:  # measured per launch on ONE GPU for one lane count: reported only for that very configuration
+                    j = json.load(open(pmc_file))
+                    if world == 1 and j.get("samples_per_pass") == args.samples_per_pass:
+                        pmc = j.get("hbm_bytes_per_launch")
                 except Exception:
                     pmc = None
             out["roofline"] = {

@@ -19,6 +19,9 @@
 
 using namespace ptv;
 
+#ifdef PTSS_CHIST
+namespace ptss { hipError_t readCandidateHist(unsigned long long* out8); }
+#endif
 namespace {
 
 thread_local std::string g_detail;
@@ -277,8 +280,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     if (cfg->tileWorld <= 0 || cfg->tileRank < 0 || cfg->tileRank >= cfg->tileWorld || cfg->bandRows <= 0)
         return fail(PTSS_EINVAL, "bad tile spec");
     const int spp = cfg->samplesPerPass == 0 ? 1 : cfg->samplesPerPass;
-    if (spp < 1 || spp > 16) return fail(PTSS_EINVAL, "samplesPerPass must be in [1, 16]");
-    if ((long long)cfg->width * cfg->height >= (1ll << 28)) return fail(PTSS_EINVAL, "frame too large (>= 2^28 pixels)");
+    if (spp < 1 || spp > 64) return fail(PTSS_EINVAL, "samplesPerPass must be in [1, 64]");
+    if ((long long)cfg->width * cfg->height >= (1ll << 26)) return fail(PTSS_EINVAL, "frame too large (>= 2^26 pixels)");
     int rc = validateScene(*scene);
     if (rc != PTSS_OK) return rc;
 
@@ -736,6 +739,10 @@ int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
 int ptss_debug_phase_cycles(ptss_context* c, unsigned long long* out8) {
     if (!c || !out8) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef PTSS_CHIST
+    HIP_TRY(ptss::readCandidateHist(out8));
+    return PTSS_OK;
+#endif
     HIP_TRY(hipMemcpy(out8, c->dTotal + 1, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTSS_OK;
 }

@@ -53,11 +53,12 @@ __device__ __forceinline__ PixelCoord locate(const TileMap& t, uint32_t local) {
     return p;
 }
 
-// Ray::pixelOffset as carried by a ray: local pixel in the low 28 bits, sample lane (0..S-1, S <= 16) above.
+// Ray::pixelOffset as carried by a ray: local pixel in the low 26 bits, sample lane (0..S-1, S <= 64) above.
 // S = cfg.samplesPerPass independent random streams per pixel are traced per pass (1 = the reference).
-constexpr uint32_t kPixMask = 0x0fffffffu;
+constexpr uint32_t kLaneShift = 26;
+constexpr uint32_t kPixMask = (1u << kLaneShift) - 1u;
 __device__ __forceinline__ uint32_t pixOf(uint32_t packed) { return packed & kPixMask; }
-__device__ __forceinline__ uint32_t laneOf(uint32_t packed) { return packed >> 28; }
+__device__ __forceinline__ uint32_t laneOf(uint32_t packed) { return packed >> kLaneShift; }
 
 struct RayRegs {
     vec3 o, d, L0, T;
@@ -250,6 +251,9 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
 // fails the discriminant test never changes `distance`, so visiting only the candidates, in the
 // same order, accepts exactly what the reference's full loop accepts — but the square-root path
 // runs a few times per lane instead of once per sphere for the whole wave.
+#ifdef PTSS_CHIST
+__device__ unsigned long long g_chist[8];
+#endif
 struct Hit {
     float distance;
     int kind, idx;  // kind: 0 none, 1 sphere, 2 triangle
@@ -272,6 +276,21 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
             if (may) mask |= 1u << j;
         }
         if (!live) mask = 0;
+#ifdef PTSS_CHIST  // diagnostic: sphere candidates per lane, wave maximum vs wave mean (tools/candidate_hist.py)
+        {
+            const uint32_t pc = (uint32_t)__builtin_popcount(mask);
+            uint32_t mx = 0;
+            while (__any(pc > mx)) ++mx;
+            uint32_t total = 0;
+            for (uint32_t b = 0; b < 6; ++b) total += (uint32_t)__popcll(__ballot((pc >> b) & 1u)) << b;
+            if (__lane_id() == 0) {
+                atomicAdd(&g_chist[0], (unsigned long long)mx);
+                atomicAdd(&g_chist[1], (unsigned long long)total);
+                atomicAdd(&g_chist[2], 1ull);
+                atomicAdd(&g_chist[3], (unsigned long long)__popcll(__ballot(live)));
+            }
+        }
+#endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -314,6 +333,21 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
         for (int j = 0; j < cnt; ++j)
             if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
         if (!live || occluded) mask = 0;
+#ifdef PTSS_CHIST
+        {
+            const uint32_t pc = (uint32_t)__builtin_popcount(mask);
+            uint32_t mx = 0;
+            while (__any(pc > mx)) ++mx;
+            uint32_t total = 0;
+            for (uint32_t b = 0; b < 6; ++b) total += (uint32_t)__popcll(__ballot((pc >> b) & 1u)) << b;
+            if (__lane_id() == 0) {
+                atomicAdd(&g_chist[4], (unsigned long long)mx);
+                atomicAdd(&g_chist[5], (unsigned long long)total);
+                atomicAdd(&g_chist[6], 1ull);
+                atomicAdd(&g_chist[7], (unsigned long long)__popcll(__ballot(live)));
+            }
+        }
+#endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -788,7 +822,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 ray.d = normalize(rotate(eye.camera.rotation, start));
                 ray.L0 = v3(0, 0, 0);
                 ray.T = v3(1, 1, 1);
-                ray.pix = pixel | (firstLane << 28);
+                ray.pix = pixel | (firstLane << kLaneShift);
                 ray.active = true;
             }
         } else {
@@ -1064,7 +1098,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
                 (void)ptrng::uniform(ray.rng);
                 (void)ptrng::uniform(ray.rng);
                 ray.L0 = v3(0, 0, 0);
-                ray.pix = i | (l << 28);
+                ray.pix = i | (l << kLaneShift);
                 finishPath(fb, ray, fb.quantTable);
             }
     } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
@@ -1123,6 +1157,9 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
     return hipGetLastError();
 }
 
+#ifdef PTSS_CHIST
+hipError_t readCandidateHist(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chist), 64); }
+#endif
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
     return ((sceneInLds ? (size_t)layout.totalVec4 : 0) + kBlockLdsVec4) * sizeof(float4);
 }

@@ -42,7 +42,7 @@ typedef struct ptss_render_config {
     /* Extension, default 1 = the reference: S independent samples per pixel per
      * ptss_generate_frame call. Sample lane l of global pixel g owns XORWOW subsequence g*S + l; every sample
      * is still tone-mapped on its own before it is summed (CudaTracer.cu:72-92); the display divides by
-     * S*(ticks - lastResetTick + 1). Lets one launch carry S times the rays (multi-GPU shards stay busy). 1..16. */
+     * S*(ticks - lastResetTick + 1). Lets one launch carry S times the rays (multi-GPU shards stay busy). 1..64. */
     int samplesPerPass;
 } ptss_render_config;
 

@@ -539,7 +539,7 @@ extern "C" {
 
 oracle_ctx* oracle_create(const ptss_scene_desc* scene, int width, int height, unsigned long long seed,
                           unsigned maxIterations, int literalSlotRng, int samplesPerPass) {
-    if (!scene || width <= 0 || height <= 0 || samplesPerPass < 1 || samplesPerPass > 16) return nullptr;
+    if (!scene || width <= 0 || height <= 0 || samplesPerPass < 1 || samplesPerPass > 64) return nullptr;
     if (literalSlotRng && samplesPerPass != 1) return nullptr;
     oracle_ctx* c = new oracle_ctx();
     c->data.defaultColor = scene->defaultColor;

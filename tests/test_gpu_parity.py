@@ -114,7 +114,9 @@ def test_tiny_frame_below_the_guard():
 @pytest.mark.parametrize("preset,w,h,bounces,ticks,S", [
     ("cornell", 96, 64, 4, 5, 2),
     ("mixed", 80, 45, 8, 4, 4),
-    ("default", 33, 17, 6, 3, 16),     # ragged frame, maximum lane count
+    ("default", 33, 17, 6, 3, 16),     # ragged frame
+    ("mixed", 48, 27, 8, 2, 40),       # the bench's lane count
+    ("cornell", 21, 13, 5, 2, 64),     # maximum lane count
     ("cornell", 8, 8, 4, 3, 2),        # 128 rays: at the loop guard (flush path with lanes)
     ("cornell", 6, 6, 4, 2, 3),        # 108 rays, non-power-of-two S: nothing runs, every stream still advances
 ])

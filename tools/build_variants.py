@@ -25,6 +25,7 @@ VARIANTS = {
     "s32": ["PTSS_SHARDS=32"],
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
+    "chist": ["PTSS_CHIST=1"],
     "nosplit": ["PTSS_SPLIT_SPARSE=0"],
     "powq": ["PTSS_QUANT_TABLE=0"],  # literal clamp/pow/scale tone map
     "blockc": ["PTSS_WAVE_COMPACT=0"],

@@ -14,7 +14,7 @@ W, H = 1920, 1080
 try:  # the PMC passes run bench.py's default workload; bench.json (written after this script) only confirms S
     SPP = json.load(open(os.path.join(src, "bench.json")))["config"]["samples_per_pass"]
 except (OSError, KeyError, ValueError):
-    SPP = 16
+    SPP = 40
 
 
 def avg(path, sub, counter):
