@@ -282,6 +282,16 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     const int spp = cfg->samplesPerPass == 0 ? 1 : cfg->samplesPerPass;
     if (spp < 1 || spp > 64) return fail(PTSS_EINVAL, "samplesPerPass must be in [1, 64]");
     if ((long long)cfg->width * cfg->height >= (1ll << 26)) return fail(PTSS_EINVAL, "frame too large (>= 2^26 pixels)");
+    {
+        // Ray planes are addressed as plane * capacity + ray in 32 bits (19 planes): the rays of one pass — local pixels
+        // x sample lanes, rounded up to whole tiles per shard — must stay below 2^32 / 19 (~226 million).
+        long long rows = 0;
+        for (int y = 0; y < cfg->height; ++y)
+            if ((y / cfg->bandRows) % cfg->tileWorld == cfg->tileRank) ++rows;
+        const unsigned long long rays = ((unsigned long long)cfg->width * rows + 255ull) / 256ull * 256ull * (unsigned long long)spp;
+        if ((rays + (unsigned long long)ptss::kShards * ptss::kBlock) * ptss::kRayPlanes >= (1ull << 32))
+            return fail(PTSS_EINVAL, "too many rays per pass: width x local rows x samplesPerPass must stay below ~226 million");
+    }
     int rc = validateScene(*scene);
     if (rc != PTSS_OK) return rc;
 

@@ -60,6 +60,23 @@ def test_default_config_and_argument_errors():
     assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
     cfg.maxIterations, cfg.tileRank, cfg.tileWorld = 4, 2, 2
     assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
+    # 32-bit ray addressing: 19 planes x rays per pass must stay below 2^32 (4K x 64 lanes does not; 4K x 16 does,
+    # and so does 4K x 64 once it is cut into 8 tiles) — refused before any device is touched
+    cfg.tileRank, cfg.tileWorld, cfg.width, cfg.height, cfg.samplesPerPass = 0, 1, 3840, 2160, 64
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
+    assert b"too many rays per pass" in L.ptss_last_error_detail()
+    cfg.samplesPerPass = 65
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
+    cfg.samplesPerPass = 16
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) in (0, -3)   # fine; -3 = no device here
+    if ctx.value:
+        L.ptss_destroy(ctx)
+        ctx = C.c_void_p()
+    cfg.samplesPerPass, cfg.tileWorld = 64, 8
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) in (0, -3)
+    if ctx.value:
+        L.ptss_destroy(ctx)
+        ctx = C.c_void_p()
     assert L.ptss_generate_frame(None, None, 1) == -1
     assert L.ptss_error_string(-3).decode() == "no usable HIP device"
     assert L.ptss_destroy(None) == 0
