@@ -35,6 +35,9 @@ __device__ __forceinline__ float asF(uint32_t u) { return __builtin_bit_cast(flo
 __device__ __forceinline__ uint32_t asU(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ vec3 xyz(float4 v) { return vec3{v.x, v.y, v.z}; }
 // orders this wave's LDS traffic for the compiler; within one wave the LDS executes in order
+// "does any lane of the wave say yes": a ballot compared with zero stays in scalar registers (s_and / s_cmp / s_cbranch);
+// hipcc's __any() round-trips the mask through a VGPR (v_cndmask + v_cmp) — two VALU instructions per triangle test
+__device__ __forceinline__ bool waveAny(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ void waveLdsFence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 struct PixelCoord {
@@ -150,6 +153,7 @@ __device__ __forceinline__ bool sphereTest(float4 sp, vec3 o, vec3 d, float limi
 // lanes it would have dropped compute values that are discarded. -----------------------------------
 struct TriHit {
     bool hit;
+    unsigned long long hitMask;  // the same verdicts as a wave mask
     float dist, w0, w1, w2;
 };
 
@@ -164,7 +168,12 @@ __device__ __forceinline__ float triRcp(float det) { return ptm::rcp(det); }
 __device__ __forceinline__ float triRcp(float det) { return ptm::rcp_if_above_1em7(det); }
 #endif
 
-__device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d, float limit, bool live) {
+// Lane predicates travel as 64-bit wave masks (one v_cmp each, combined with scalar ANDs, carried over the wave-uniform
+// branch in SGPRs, turned back into a lane predicate for free by inverse_ballot). As bools they made hipcc round-trip
+// through a VGPR — v_cndmask + v_cmp — every time a compound condition met a ballot: twice per triangle.
+__device__ __forceinline__ unsigned long long maskOf(bool directCompare) { return __builtin_amdgcn_ballot_w64(directCompare); }
+
+__device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d, float limit, unsigned long long liveMask) {
     const vec3 v0 = xyz(tr.a), e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
@@ -172,16 +181,19 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     const vec3 s = o - v0;
     const vec3 r = cross(s, e1);
     const float dist = dot(e2, r) * inverseDet;
-    const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
+    // pass = live && !(|det| <= 1e-7) && !(dist <= 0 || dist > limit), Primitives.h:41-42, :51-52
+    const unsigned long long passMask = liveMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > limit));
     TriHit h;
     h.hit = false;
+    h.hitMask = 0ull;
     h.dist = dist;
     h.w0 = h.w1 = h.w2 = 0;
-    if (__any(pass)) {
+    if (passMask != 0ull) {
         const float b1 = dot(s, q) * inverseDet;
         const float b2 = dot(d, r) * inverseDet;
         const float b0 = 1.0f - (b1 + b2);
-        h.hit = pass && !((b0 < 0) || (b1 < 0) || (b2 < 0));
+        h.hitMask = passMask & maskOf(!(b0 < 0)) & maskOf(!(b1 < 0)) & maskOf(!(b2 < 0));
+        h.hit = __builtin_amdgcn_inverse_ballot_w64(h.hitMask);
         h.w0 = b0;
         h.w1 = b1;
         h.w2 = b2;
@@ -222,22 +234,24 @@ __device__ __forceinline__ bool sphereTestPrimary(float4 pv, vec3 d, float limit
 }
 
 __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 ps /* s, dot(e2,r) */, float4 pr /* r */,
-                                                      vec3 d, float limit, bool live) {
+                                                      vec3 d, float limit, unsigned long long liveMask) {
     const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
     const vec3 q = cross(d, e2);
     const float det = dot(e1, q);
     const float inverseDet = triRcp(det);  // 1 / det, Primitives.h:44; unused when |det| <= 1e-7
     const float dist = ps.w * inverseDet;
-    const bool pass = live && !(ptm::abs(det) <= 1e-7f) && !((dist <= 0.0f) || (dist > limit));
+    const unsigned long long passMask = liveMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > limit));
     TriHit h;
     h.hit = false;
+    h.hitMask = 0ull;
     h.dist = dist;
     h.w0 = h.w1 = h.w2 = 0;
-    if (__any(pass)) {
+    if (passMask != 0ull) {
         const float b1 = dot(xyz(ps), q) * inverseDet;
         const float b2 = dot(d, xyz(pr)) * inverseDet;
         const float b0 = 1.0f - (b1 + b2);
-        h.hit = pass && !((b0 < 0) || (b1 < 0) || (b2 < 0));
+        h.hitMask = passMask & maskOf(!(b0 < 0)) & maskOf(!(b1 < 0)) & maskOf(!(b2 < 0));
+        h.hit = __builtin_amdgcn_inverse_ballot_w64(h.hitMask);
         h.w0 = b0;
         h.w1 = b1;
         h.w2 = b2;
@@ -304,11 +318,12 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
             }
         }
     }
+    const unsigned long long liveMask = maskOf(live);
     for (int i = 0; i < L.numTriangles; ++i) {
         const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
         const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], sc[L.offPrimTri + 2 * i + 1], d,
-                                                         h.distance, live)
-                                   : triangleTest(tcur, o, d, h.distance, live);
+                                                         h.distance, liveMask)
+                                   : triangleTest(tcur, o, d, h.distance, liveMask);
         if (th.hit) {
             h.distance = th.dist;
             h.kind = 2;
@@ -358,13 +373,16 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
             }
         }
     }
+    unsigned long long need = maskOf(live) & ~maskOf(occluded);  // lanes that still want an answer
+    unsigned long long blocked = 0ull;
     for (int i = 0; i < L.numTriangles; ++i) {
-        if (!__any(live && !occluded)) break;
+        if (need == 0ull) break;
         const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
-        const TriHit th = triangleTest(tcur, lo, w_i, distance, live && !occluded);
-        occluded = occluded || th.hit;
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, need);
+        blocked |= th.hitMask;
+        need &= ~th.hitMask;
     }
-    return occluded;
+    return occluded || __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
 // ---- the same any-hit with the primitive list SPLIT over g = 1 << shift lanes per segment: lane `sub` of a
@@ -397,15 +415,18 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
         }
     }
     const int triSteps = (L.numTriangles + g - 1) >> shift;
+    unsigned long long need = maskOf(live) & ~maskOf(occluded);
+    unsigned long long blocked = 0ull;
     for (int k = 0; k < triSteps; ++k) {
-        if (!__any(live && !occluded)) break;
+        if (need == 0ull) break;
         const int idx = (k << shift) + sub;
         const bool in = idx < L.numTriangles;
         const TriRows tcur = loadTri(sc + L.offTri + 3 * (in ? idx : 0));
-        const TriHit th = triangleTest(tcur, lo, w_i, distance, live && in && !occluded);
-        occluded = occluded || th.hit;
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, need & maskOf(in));
+        blocked |= th.hitMask;
+        need &= ~th.hitMask;
     }
-    return occluded;
+    return occluded || __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
