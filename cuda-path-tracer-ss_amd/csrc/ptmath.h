@@ -52,6 +52,13 @@ PTM_HD float abs(float x) { return __builtin_fabsf(x); }
 // IEEE result by exhaustion over every float32 in the range (tests/csrc/math_exhaustive.hip, run by
 // tests/test_gpu_math.py on the GPU the tests run on); outside the range they fall back to the IEEE
 // sequence. Ranges (biased exponent): rcp [2, 252], sqrt [32, 222].
+#if defined(__HIP_DEVICE_COMPILE__)
+// Range guards are evaluated as wave masks: one ballot per DIRECT compare, combined with scalar ANDs and held against the
+// mask of active lanes. (A compound bool handed to a ballot makes hipcc materialise it in a VGPR and compare it again:
+// v_cndmask + v_cmp at every guarded operation.) `allLanes(m)`: every active lane has its bit set in m.
+PTM_HD unsigned long long lanes(bool directCompare) { return __builtin_amdgcn_ballot_w64(directCompare); }
+PTM_HD bool allLanes(unsigned long long m) { return m == __builtin_amdgcn_ballot_w64(true); }
+#endif
 PTM_HD float sqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y = __builtin_amdgcn_rsqf(x);
@@ -59,9 +66,9 @@ PTM_HD float sqrt(float x) {
     const float h = 0.5f * y;
     const float r = __builtin_fmaf(-s, s, x);
     float out = __builtin_fmaf(r, h, s);
-    const bool inRange = x >= 2.5243549e-29f /* 2^-95 */ && x < 7.9228163e28f /* 2^96 */;
+    const bool lo = x >= 2.5243549e-29f /* 2^-95 */, hi = x < 7.9228163e28f /* 2^96 */;
     // wave-uniform escape: only a wave holding an out-of-range operand runs the IEEE sequence at all
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) out = inRange ? out : __builtin_sqrtf(x);
+    if (__builtin_expect(!allLanes(lanes(lo) & lanes(hi)), 0)) out = (lo && hi) ? out : __builtin_sqrtf(x);
     return out;
 #else
     return __builtin_sqrtf(x);
@@ -73,8 +80,8 @@ PTM_HD float rcp(float x) {
     const float e = __builtin_fmaf(-x, r0, 1.0f);
     float out = __builtin_fmaf(e, r0, r0);
     const float ax = __builtin_fabsf(x);
-    const bool inRange = ax >= 2.3509887e-38f /* 2^-125 */ && ax < 8.5070592e37f /* 2^126 */;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) out = inRange ? out : 1.0f / x;
+    const bool lo = ax >= 2.3509887e-38f /* 2^-125 */, hi = ax < 8.5070592e37f /* 2^126 */;
+    if (__builtin_expect(!allLanes(lanes(lo) & lanes(hi)), 0)) out = (lo && hi) ? out : 1.0f / x;
     return out;
 #else
     return 1.0f / x;
@@ -89,7 +96,7 @@ PTM_HD float rcp_if_above_1em7(float x) {
     const float e = __builtin_fmaf(-x, r0, 1.0f);
     float out = __builtin_fmaf(e, r0, r0);
     const bool inRange = __builtin_fabsf(x) < 8.5070592e37f /* 2^126 */;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) out = inRange ? out : 1.0f / x;
+    if (__builtin_expect(!allLanes(lanes(inRange)), 0)) out = inRange ? out : 1.0f / x;
     return out;
 #else
     return 1.0f / x;
@@ -110,6 +117,10 @@ PTM_HD bool div_in_range(float x) {
     const float ax = __builtin_fabsf(x);
     return ax >= 8.6736174e-19f /* 2^-60 */ && ax < 1.1529215e18f /* 2^60 */;
 }
+PTM_HD unsigned long long div_range_lanes(float x) {  // the same test as a wave mask
+    const float ax = __builtin_fabsf(x);
+    return lanes(ax >= 8.6736174e-19f) & lanes(ax < 1.1529215e18f);
+}
 PTM_HD float rcp_core(float b) {  // only for operands already known to be in range
     const float r0 = __builtin_amdgcn_rcpf(b);
     const float e = __builtin_fmaf(-b, r0, 1.0f);
@@ -124,8 +135,7 @@ PTM_HD float div_core(float a, float b, float r) {
 PTM_HD float div(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float q = div_core(a, b, rcp_core(b));
-    const bool inRange = div_in_range(a) && div_in_range(b);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) q = inRange ? q : a / b;
+    if (__builtin_expect(!allLanes(div_range_lanes(a) & div_range_lanes(b)), 0)) q = (div_in_range(a) && div_in_range(b)) ? q : a / b;
     return q;
 #else
     return a / b;
@@ -138,8 +148,8 @@ PTM_HD void div3(float ax, float ay, float az, float b, float& qx, float& qy, fl
     qx = div_core(ax, b, r);
     qy = div_core(ay, b, r);
     qz = div_core(az, b, r);
-    const bool inRange = div_in_range(b) && div_in_range(ax) && div_in_range(ay) && div_in_range(az);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0, 0)) {
+    if (__builtin_expect(!allLanes(div_range_lanes(b) & div_range_lanes(ax) & div_range_lanes(ay) & div_range_lanes(az)), 0)) {
+        const bool inRange = div_in_range(b) && div_in_range(ax) && div_in_range(ay) && div_in_range(az);
         qx = inRange ? qx : ax / b;
         qy = inRange ? qy : ay / b;
         qz = inRange ? qz : az / b;
