@@ -186,3 +186,29 @@ def test_custom_scene_from_raw_records(num_spheres):
     assert np.array_equal(r.accumulator(), o.accumulator())
     assert _eq_nan(r.float_accumulator(), o.float_sum())
     r.close()
+
+
+def test_bench_workload_at_full_size_equals_oracle():
+    """BASELINE.json configs[2] exactly as bench.py runs it — 1920x1080, 'mixed', 8 bounces, seed 0x5EED — against the
+    oracle for every pixel: two passes at one sample per tick, then one pass at the bench's 40 sample lanes (83 M
+    streams; ~10 s of oracle time on the GPU box's cores)."""
+    scene = ptss.Scene("mixed")
+    w, h, bounces = 1920, 1080, 8
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces)
+    for _ in range(2):
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts())
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    r.close()
+    del o
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, samples_per_pass=40, sync_each_frame=False)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=40)
+    r.generate_frame()
+    o.generate_frame()
+    assert np.array_equal(r.live_counts(), o.live_counts())
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert r.total_ray_bounces() == o.total_ray_bounces()
+    r.close()
