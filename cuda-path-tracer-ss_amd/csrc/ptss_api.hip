@@ -79,7 +79,7 @@ struct ptss_context {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
     int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
-    int gridCap = 1280;          // workgroups per shard at most (PTSS_GRID_CAP overrides; 0 = uncapped)
+    int gridCap = 1792;          // workgroups per shard at most (PTSS_GRID_CAP overrides; 0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
     uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
@@ -516,9 +516,10 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             const unsigned long long want = tilesPerShard * ptss::kShards;
             if (want < (unsigned long long)blocks) blocks = (int)want;
         }
-        // Launches wider than 16 resident rounds (256 CUs x 5 workgroups) stop growing: beyond that a workgroup walks
-        // several tiles and stages the scene into LDS once for all of them (+1.7 % at 16 samples per pass; the cap never
-        // binds at 1080p with one sample per pass). PTSS_GRID_CAP=<workgroups per shard> overrides, 0 = no cap.
+        // Launches wider than 16 resident rounds (256 CUs x 7 workgroups = 1,792 per round, 1,792 per shard in all) stop
+        // growing: beyond that a workgroup walks several tiles and stages the scene into LDS once for all of them (+2 % at
+        // 16-40 samples per pass against uncapped, flat from 896 to 3,584; the cap never binds at 1080p with one sample
+        // per pass). PTSS_GRID_CAP=<workgroups per shard> overrides, 0 = no cap.
         if (c->gridCap > 0 && c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
         EventPair ev{nullptr, nullptr};
         if (c->cfg.timeKernels) {
