@@ -15,6 +15,8 @@
 
 #include "ptss.h"
 #include "ptss_device.h"
+#include <algorithm>
+#include <cmath>
 #include "ptquant.h"
 
 using namespace ptv;
@@ -53,7 +55,11 @@ struct ptss_context {
     hipStream_t stream = nullptr;
     ptss::TileMap tile{};
     ptss::SceneLayout layout{};
-    float4* dScene = nullptr;
+    float4* dScene = nullptr;       // the scene image the frames use
+    float4* dSceneAlt = nullptr;    // with sphere acceleration on: the plain image, for cameras outside its range
+    ptss::SceneLayout layoutAlt{};
+    bool sceneInLdsAlt = true;
+    bool haveAccel = false, accelActive = false;
     float* dPool[2] = {nullptr, nullptr};
     uint32_t* dRngHome = nullptr;
     uint32_t* dCounts = nullptr;
@@ -96,16 +102,92 @@ struct ptss_context {
 
 namespace {
 
-void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float4>& blob) {
+// ---- sphere acceleration (scenes with many spheres) ------------------------------------------------------------------
+// The kernel may skip a sphere only if the discriminant the reference computes for it (Primitives.h:107-118, float32)
+// is certainly negative. Spheres are sorted along a Morton curve and cut into chunks of kChunkSpheres; each chunk gets
+// a bounding sphere (C, R) with |c_i - C| + r_i <= R for its members. For a ray (o, d) with | |d|^2 - 1 | <= eps = 1e-5
+// let vC = o - C, vv = vC.vC, dv = d.vC. The kernel culls the chunk iff
+//       vv (1 - mu) - (1 + 2 eps) dv^2  >  R^2 (1 + m)^3        with m = 5e-3, mu = m + m^2.
+// Why that is safe: the left side minus mu vv bounds the squared distance D^2 of C from the ray's line from below, and
+// R^2 (1+m)^3 + mu vv >= (R + m (|vC| + R))^2 (AM-GM), so D > R + m (|vC| + R). A member's centre is then farther
+// than r_i + m |v_i| from the line (|v_i| <= |vC| + R), i.e. dist_i^2 > r_i^2 + 2.5e-5 |v_i|^2, while its exact
+// discriminant / 4 is r_i^2 - dist_i^2 + (|d|^2 - 1)(d^.v_i)^2 <= r_i^2 - dist_i^2 + 1e-5 |v_i|^2 < -1.5e-5 |v_i|^2;
+// float32 evaluation moves it by less than 1e-6 |v_i|^2 (|v_i| > r_i here). Rays whose direction is not unit to 1e-5
+// (the reference does not renormalise blended vertex normals) visit every chunk; a NaN anywhere fails the `>`.
+// Requires finite, moderate geometry (|coordinate|, radius <= 1e15) so that no discriminant overflows; packScene and
+// the per-frame camera check fall back to the plain image otherwise.
+constexpr double kAccelM = 5e-3;
+constexpr float kAccelLimit = 1e15f;
+constexpr int kAccelMinSpheres = 64;
+
+bool accelEligible(const ptss_scene_desc& s) {
+    if (s.numSpheres < (size_t)kAccelMinSpheres) return false;
+    auto ok = [](float v) { return std::fabs(v) <= kAccelLimit; };  // false for NaN and infinities as well
+    for (size_t i = 0; i < s.numSpheres; ++i) {
+        const ptss_sphere& sp = s.spheres[i];
+        if (!ok(sp.position.x) || !ok(sp.position.y) || !ok(sp.position.z) || !ok(sp.radius)) return false;
+    }
+    for (size_t i = 0; i < s.numTriangles; ++i) {
+        const ptss_triangle& t = s.triangles[i];
+        for (const ptss_vec3* v : {&t.vertex0, &t.vertex1, &t.vertex2})
+            if (!ok(v->x) || !ok(v->y) || !ok(v->z)) return false;
+    }
+    for (size_t i = 0; i < s.numPointLights; ++i)
+        if (!ok(s.pointLights[i].position.x) || !ok(s.pointLights[i].position.y) || !ok(s.pointLights[i].position.z)) return false;
+    return true;
+}
+
+// sorted position -> original index, along a 30-bit Morton curve over the box of the centres (ties by original index)
+std::vector<int> mortonOrder(const ptss_scene_desc& s) {
+    const int n = (int)s.numSpheres;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; ++i) {
+        const double c[3] = {s.spheres[i].position.x, s.spheres[i].position.y, s.spheres[i].position.z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+        }
+    }
+    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+        v &= 0x3ffu;
+        v = (v | (v << 16)) & 0x030000ffu;
+        v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<std::pair<uint32_t, int>> keyed(n);
+    for (int i = 0; i < n; ++i) {
+        const double c[3] = {s.spheres[i].position.x, s.spheres[i].position.y, s.spheres[i].position.z};
+        uint32_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = hi[a] - lo[a];
+            const double f = ext > 0 ? (c[a] - lo[a]) / ext : 0.0;
+            code |= spread((uint32_t)std::min(1023.0, std::max(0.0, f * 1024.0))) << a;
+        }
+        keyed[i] = {code, i};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = keyed[i].second;
+    return order;
+}
+
+void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float4>& blob, bool accel) {
     auto u2f = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    L.accelSpheres = accel ? 1 : 0;
+    L.numChunks = accel ? (int)((s.numSpheres + ptss::kChunkSpheres - 1) / ptss::kChunkSpheres) : 0;
+    const int sphereRows = accel ? L.numChunks * ptss::kChunkSpheres : (int)s.numSpheres;
     L.numSpheres = (int)s.numSpheres;
     L.numTriangles = (int)s.numTriangles;
     L.numMaterials = (int)s.numMaterials;
     L.numPointLights = (int)s.numPointLights;
     L.numAreaLights = (int)s.numAreaLights;
     int off = 0;
-    L.offSphere = off;      off += L.numSpheres;
-    L.offSphereMat = off;   off += (L.numSpheres + 3) / 4;
+    L.offSphere = off;      off += sphereRows;
+    L.offSphereMat = off;   off += (sphereRows + 3) / 4;
+    L.offSphereOrig = off;  off += accel ? (sphereRows + 3) / 4 : 0;
+    L.offChunk = off;       off += L.numChunks;
     L.offTri = off;         off += 3 * L.numTriangles;
     L.offTriNormal = off;   off += 3 * L.numTriangles;
     L.offTriVert = off;     off += 2 * L.numTriangles;
@@ -113,7 +195,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
     L.offQuant = off;       off += ptq::kTableFloats / 4;
-    L.offPrimSphere = off;  off += L.numSpheres;
+    L.offPrimSphere = off;  off += accel ? 0 : L.numSpheres;  // the chunked traversal has no camera-origin shortcut
     L.offPrimTri = off;     off += 2 * L.numTriangles;
     L.totalVec4 = off;
     auto finite3 = [](const ptss_vec3& v) { return v.x - v.x == 0.0f && v.y - v.y == 0.0f && v.z - v.z == 0.0f; };
@@ -126,11 +208,36 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
     ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));
-    for (int i = 0; i < L.numSpheres; ++i) {
-        const ptss_sphere& sp = s.spheres[i];
+    std::vector<int> order;
+    if (accel) {
+        order = mortonOrder(s);
+        while ((int)order.size() < sphereRows) order.push_back(order.back());  // pad the last chunk with copies
+    } else {
+        order.resize(s.numSpheres);
+        for (size_t i = 0; i < s.numSpheres; ++i) order[i] = (int)i;
+    }
+    for (int i = 0; i < sphereRows; ++i) {
+        const ptss_sphere& sp = s.spheres[order[i]];
         // radius*radius is the same single rounding the reference performs per test (Primitives.h:113)
         blob[L.offSphere + i] = float4{sp.position.x, sp.position.y, sp.position.z, sp.radius * sp.radius};
         reinterpret_cast<int*>(&blob[L.offSphereMat])[i] = sp.materialIdx;
+        if (accel) reinterpret_cast<int*>(&blob[L.offSphereOrig])[i] = order[i];
+    }
+    for (int k = 0; k < L.numChunks; ++k) {  // bounding sphere of the chunk, in double, rounded outwards
+        double C[3] = {0, 0, 0};
+        for (int j = 0; j < ptss::kChunkSpheres; ++j) {
+            const ptss_sphere& sp = s.spheres[order[k * ptss::kChunkSpheres + j]];
+            C[0] += sp.position.x; C[1] += sp.position.y; C[2] += sp.position.z;
+        }
+        const float Cf[3] = {(float)(C[0] / ptss::kChunkSpheres), (float)(C[1] / ptss::kChunkSpheres), (float)(C[2] / ptss::kChunkSpheres)};
+        double Rmax = 0;
+        for (int j = 0; j < ptss::kChunkSpheres; ++j) {
+            const ptss_sphere& sp = s.spheres[order[k * ptss::kChunkSpheres + j]];
+            const double dx = (double)sp.position.x - Cf[0], dy = (double)sp.position.y - Cf[1], dz = (double)sp.position.z - Cf[2];
+            Rmax = std::max(Rmax, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)sp.radius));
+        }
+        const double infl = Rmax * Rmax * (1 + kAccelM) * (1 + kAccelM) * (1 + kAccelM) * (1 + 1e-9);
+        blob[L.offChunk + k] = float4{Cf[0], Cf[1], Cf[2], std::nextafter((float)infl, INFINITY)};
     }
     for (int i = 0; i < L.numTriangles; ++i) {
         const ptss_triangle& t = s.triangles[i];
@@ -343,11 +450,17 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         }
     }
 
-    std::vector<float4> blob;
-    packScene(*scene, c->layout, blob);
+    // Scenes with many spheres get the chunked image (see accelEligible / packScene); PTSS_SPHERE_ACCEL=0 keeps the plain one
+    bool wantAccel = accelEligible(*scene);
+    if (const char* e = getenv("PTSS_SPHERE_ACCEL")) wantAccel = wantAccel && atoi(e) != 0;
+    std::vector<float4> blob, blobAlt;
+    packScene(*scene, c->layout, blob, wantAccel);
+    if (wantAccel) packScene(*scene, c->layoutAlt, blobAlt, false);
+    c->haveAccel = c->accelActive = wantAccel;
     // Scenes whose image fits the default 64 KiB dynamic-LDS window are staged in LDS; larger ones are read in place
     // (wave-uniform scalar loads + per-lane gathers from global memory) — same kernel, same results, no size limit.
     const bool sceneFitsLds = ptss::bounceLdsBytes(c->layout, true) <= 64 * 1024;
+    const bool sceneFitsLdsAlt = wantAccel && ptss::bounceLdsBytes(c->layoutAlt, true) <= 64 * 1024;
 
 #define CREATE_TRY(expr)                                  \
     do {                                                  \
@@ -361,6 +474,10 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
 
     CREATE_TRY(hipMalloc(&c->dScene, blob.size() * sizeof(float4)));
     CREATE_TRY(hipMemcpy(c->dScene, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (wantAccel) {
+        CREATE_TRY(hipMalloc(&c->dSceneAlt, blobAlt.size() * sizeof(float4)));
+        CREATE_TRY(hipMemcpy(c->dSceneAlt, blobAlt.data(), blobAlt.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     const size_t poolBytes = (size_t)ptss::kRayPlanes * c->poolStride * sizeof(float);
     CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
     CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
@@ -408,9 +525,10 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     // s_load through the scalar cache) is kept for A/B runs via PTSS_SCENE_PATH=scalar; on the
     // 38-primitive "mixed" scene it measured 16 % slower (profiles/README.md, r01).
     c->sceneInLds = sceneFitsLds;
+    c->sceneInLdsAlt = sceneFitsLdsAlt;
     if (const char* e = getenv("PTSS_SCENE_PATH")) {
         if (!strcmp(e, "lds")) c->sceneInLds = sceneFitsLds;
-        if (!strcmp(e, "scalar")) c->sceneInLds = false;
+        if (!strcmp(e, "scalar")) c->sceneInLds = c->sceneInLdsAlt = false;
     }
     c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
     if (const char* e = getenv("PTSS_GRID_CAP")) c->gridCap = atoi(e);
@@ -437,6 +555,7 @@ int ptss_destroy(ptss_context* c) {
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     (void)hipFree(c->dScene);
+    (void)hipFree(c->dSceneAlt);
     (void)hipFree(c->dPool[0]);
     (void)hipFree(c->dPool[1]);
     (void)hipFree(c->dRngHome);
@@ -463,6 +582,17 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         return PTSS_OK;
     }
 
+    if (c->haveAccel) {  // the chunked image assumes a camera within the geometry's magnitude range (packScene)
+        auto inRange = [](float v) { return std::fabs(v) <= kAccelLimit; };
+        const bool want = inRange(c->camera.position.x) && inRange(c->camera.position.y) && inRange(c->camera.position.z);
+        if (want != c->accelActive) {
+            std::swap(c->dScene, c->dSceneAlt);
+            std::swap(c->layout, c->layoutAlt);
+            std::swap(c->sceneInLds, c->sceneInLdsAlt);
+            c->accelActive = want;
+            c->cameraDirty = true;
+        }
+    }
     if (c->resetTicksThisFrame) {  // CudaTracer.cu:602-608
         c->lastResetTick = ticks;
         HIP_TRY(ptss::launchClear(st, frameBuffers(c, pixels, 0)));

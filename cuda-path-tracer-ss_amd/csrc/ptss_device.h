@@ -64,6 +64,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_SHARDS 16
 #endif
 constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workgroup
+#ifndef PTSS_CHUNK
+#define PTSS_CHUNK 8
+#endif
+constexpr int kChunkSpheres = PTSS_CHUNK;   // spheres per chunk of the many-sphere traversal (4 / 8 / 16 measured)
 constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
 constexpr int kCountStride = 32;            // one counter per 128-B line
 constexpr int kCountWords = (kMaxBounces + 1) * kShards * kCountStride;
@@ -76,7 +80,8 @@ constexpr uint32_t kMinLiveRays = 128;  // loop guard `numRays > 128`, CudaTrace
 struct SceneLayout {
     int numSpheres, numTriangles, numMaterials, numPointLights, numAreaLights;
     // offsets in float4 units
-    int offSphere;      // S x {cx, cy, cz, radius^2}
+    int offSphere;      // S x {cx, cy, cz, radius^2}; with accelSpheres: the spheres in spatially sorted order, padded to whole
+                        // chunks of kChunkSpheres with copies of the last one
     int offSphereMat;   // ceil(S/4) x 4 ints
     int offTri;         // T x 3: {v0.xyz, bits(materialIdx)}, {e1.xyz, 0}, {e2.xyz, 0}
     int offTriNormal;   // T x 3: {n0,0},{n1,0},{n2,0}
@@ -85,6 +90,12 @@ struct SceneLayout {
                         //        {emmitance, roughness},{specularExponent, indexOfRefraction, bits(flags), 0}
     int offPointLight;  // P x 2: {position,0},{power,0}
     int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
+    // Sphere acceleration (scenes with many spheres; packScene decides): chunks of kChunkSpheres consecutive sorted spheres
+    // with a conservative bounding sphere each; a lane visits only the chunks its ray can touch (ptss_kernels.hip).
+    int accelSpheres;   // 0: every sphere is tested by every ray (the reference's loop); 1: chunked
+    int numChunks;
+    int offChunk;       // numChunks x {Cx, Cy, Cz, inflated R^2}
+    int offSphereOrig;  // ints: original (caller's) index of each sorted sphere — decides ties the way the reference's order does
     int offQuant;       // 65 rows: the 8-bit tone-map thresholds T[0..256] (ptquant.h), read by finishPath
     int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
     int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}

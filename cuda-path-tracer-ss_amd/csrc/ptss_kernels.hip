@@ -274,14 +274,123 @@ struct Hit {
     float w0, w1, w2;
 };
 
-template <bool kPrimary>
+// ---- Scenes with many spheres (SceneLayout::accelSpheres; derivation of the test and of its constants: packScene in
+// ptss_api.hip). The spheres sit in spatially sorted chunks of kChunkSpheres with a bounding sphere each. chunkMask is
+// the wave-uniform pass over 32 chunk bounds: bit k = "this lane's ray may touch chunk k" — a conservative test that
+// only ever skips spheres whose reference discriminant is certainly negative. Each lane then walks ITS chunks (per-lane
+// gathers) with the reference's own tests. The visiting order is no longer the reference's, which matters only when two
+// spheres are hit at exactly the same distance: the sequential `<=` rule ends on the HIGHEST index among them, so the
+// closest hit keeps (minimum distance, highest original index) — identical for the finite distances this mode is
+// restricted to.
+constexpr float kAccelMu = 5e-3f + 5e-3f * 5e-3f;   // m + m^2
+constexpr float kAccelDirEps = 1e-5f;               // | |d|^2 - 1 | up to which a direction counts as unit
+constexpr float kAccelDvScale = 1.0f + 2e-5f;       // 1 / (1 - eps) rounded up
+
+__device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec3 o, vec3 d, bool unitDir) {
+    uint32_t mask = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const float4 b = bounds[k];
+        const vec3 v = o - xyz(b);
+        const float dv = dot(d, v);
+        const float vv = dot(v, v);
+        const float lhs = vv * (1.0f - kAccelMu) - kAccelDvScale * (dv * dv);
+        if (!(lhs > b.w)) mask |= 1u << k;  // not provably clear of the chunk (NaN lands here too)
+    }
+    return unitDir ? mask : ((cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u));
+}
+
+// The chunk bits of up to 128 chunks (4 words) are gathered first and walked in ONE per-lane loop: the wave then runs as
+// long as its busiest lane's TOTAL, not the sum over 32-chunk groups of each group's busiest lane.
+struct ChunkBits {
+    uint32_t w[4];
+};
+__device__ __forceinline__ ChunkBits chunkBits128(const float4* sc, const SceneLayout& L, int g0, vec3 o, vec3 d, bool unitDir, bool live) {
+    ChunkBits b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = g0 + 32 * q;
+        const int left = L.numChunks - g;  // wave-uniform
+        b.w[q] = (left > 0) ? chunkMask(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
+        if (!live) b.w[q] = 0u;
+    }
+    return b;
+}
+__device__ __forceinline__ bool anyChunk(const ChunkBits& b) { return (b.w[0] | b.w[1] | b.w[2] | b.w[3]) != 0u; }
+__device__ __forceinline__ int popChunk(ChunkBits& b) {  // lowest set bit, removed
+    const int q = b.w[0] ? 0 : (b.w[1] ? 1 : (b.w[2] ? 2 : 3));
+    const uint32_t word = q == 0 ? b.w[0] : (q == 1 ? b.w[1] : (q == 2 ? b.w[2] : b.w[3]));
+    const int k = __builtin_ctz(word);
+    const uint32_t rest = word & (word - 1u);
+    b.w[0] = q == 0 ? rest : b.w[0];
+    b.w[1] = q == 1 ? rest : b.w[1];
+    b.w[2] = q == 2 ? rest : b.w[2];
+    b.w[3] = q == 3 ? rest : b.w[3];
+    return 32 * q + k;
+}
+
+__device__ __forceinline__ void closestSpheresChunked(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h) {
+    const int* orig = reinterpret_cast<const int*>(sc + L.offSphereOrig);
+    const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
+    int bestOrig = -1;
+    for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
+        ChunkBits chunks = chunkBits128(sc, L, g0, o, d, unitDir, live);
+        while (anyChunk(chunks)) {
+            const int base = (g0 + popChunk(chunks)) * kChunkSpheres;
+            uint32_t mask = 0;
+            for (int j = 0; j < kChunkSpheres; ++j)
+                if (sphereMayHit(sc[L.offSphere + base + j], o, d)) mask |= 1u << j;
+            while (mask != 0) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                float t;
+                if (sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t)) {  // t <= h.distance
+                    const int who = orig[base + j];
+                    if (t < h.distance || who > bestOrig) {
+                        h.distance = t;
+                        h.kind = 1;
+                        h.idx = base + j;
+                        bestOrig = who;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, bool live) {
+    const bool unitDir = ptm::abs(dot(w_i, w_i) - 1.0f) <= kAccelDirEps;
+    bool occluded = false;
+    for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
+        ChunkBits chunks = chunkBits128(sc, L, g0, lo, w_i, unitDir, live && !occluded);
+        while (anyChunk(chunks)) {
+            const int base = (g0 + popChunk(chunks)) * kChunkSpheres;
+            uint32_t mask = 0;
+            for (int j = 0; j < kChunkSpheres; ++j)
+                if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
+            while (mask != 0) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                float t;
+                if (sphereTest(sc[L.offSphere + base + j], lo, w_i, distance, t)) {
+                    occluded = true;
+                    mask = 0;
+                    chunks.w[0] = chunks.w[1] = chunks.w[2] = chunks.w[3] = 0u;
+                }
+            }
+        }
+    }
+    return occluded;
+}
+
+template <bool kPrimary, bool kAccel>
 __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live) {
     Hit h;
     h.distance = ptm::inf();
     h.kind = 0;
     h.idx = 0;
     h.w0 = h.w1 = h.w2 = 0;
-    for (int base = 0; base < L.numSpheres; base += 32) {
+    if constexpr (kAccel) closestSpheresChunked(sc, L, o, d, live, h);
+    for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
         uint32_t mask = 0;
         for (int j = 0; j < cnt; ++j) {
@@ -339,10 +448,12 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L
 // ---- the any-hit loops of lineOfSight, CudaTracer.cu:437-452: true when some primitive blocks the
 // segment. Order-independent (the reference returns at the first accepted primitive and no test
 // depends on another). `live`: this lane carries a segment. -----------------------------------------
+template <bool kAccel>
 __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance,
                                        bool live) {
     bool occluded = false;
-    for (int base = 0; base < L.numSpheres; base += 32) {
+    if constexpr (kAccel) occluded = anySphereChunked(sc, L, lo, w_i, distance, live);
+    for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
         uint32_t mask = 0;
         for (int j = 0; j < cnt; ++j)
@@ -734,7 +845,7 @@ __global__ void displayKernel(FrameBuffers fb) {
 // Origin-only parts of the primary-ray tests, one thread per primitive; rerun when the camera moves.
 __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3 origin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < L.numSpheres) {
+    if (i < L.numSpheres && !L.accelSpheres) {
         const float4 sp = blob[L.offSphere + i];
         const vec3 v = origin - xyz(sp);
         blob[L.offPrimSphere + i] = float4{v.x, v.y, v.z, dot(v, v) - sp.w};
@@ -773,8 +884,11 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // kFirst: bounce 0 makes its own rays — computeEyeRaysKernel (CudaTracer.cu:51-61, 321-343) is fused in: the
 // lane fetches its pixel's random stream from the home record, draws the two jitter samples, builds the
 // eye ray in registers (no ray pool read) and intersects with the camera-origin precomputes.
-template <bool kLast, bool kSceneInLds, bool kFirst>
-__global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffers fb, const float4* __restrict__ sceneBlob,
+// kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
+// that scenes without it run exactly the code they ran before.
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
+__global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
+   FrameBuffers fb, const float4* __restrict__ sceneBlob,
                                                                       SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
     extern __shared__ float4 lds[];
     const uint32_t shard = blockIdx.x % kShards;
@@ -859,7 +973,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit<kFirst>(sc, L, ray.o, ray.d, valid);
+        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, L, ray.o, ray.d, valid);
 #endif
         PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
@@ -959,7 +1073,8 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
             for (uint32_t e0 = 0; e0 < queued;) {
                 const uint32_t rem = queued - e0;
                 const uint32_t units = (rem + 7u) >> 3;  // of 8 segments
-                const int chunkLog = units >= 7u ? 6 : (units >= 4u ? 5 : (units >= 2u ? 4 : 3));
+                // (the chunked sphere traversal is per lane already: those scenes take dense passes only)
+                const int chunkLog = (units >= 7u || kAccel) ? 6 : (units >= 4u ? 5 : (units >= 2u ? 4 : 3));
                 const int shift = 6 - chunkLog;                      // lanes per segment = 1 << shift
                 const uint32_t mine = lane >> shift;                 // this lane's segment within the chunk
                 const uint32_t sub = lane & ((1u << shift) - 1u);    // its share of the primitive list
@@ -968,7 +1083,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
                 const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
                 const float reach = wq[6 * kQueueCap + es];
-                const bool occ = (shift == 0) ? anyHit(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+                const bool occ = (shift == 0) ? anyHit<kAccel>(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
                 const unsigned long long verdicts = __ballot(occ);  // all lanes vote before anyone branches
                 const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
                 if (have && sub == 0u && (verdicts & group) != 0ull) {
@@ -984,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, PTSS_MINWAVES) void bounceKernel(FrameBuffe
                 const uint32_t es = have ? e : 0u;
                 const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
                 const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
-                const bool occ = anyHit(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
+                const bool occ = anyHit<kAccel>(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
                 if (have && occ) {
                     const uint32_t ow = wqOwner[es];
                     wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
@@ -1169,11 +1284,11 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
     return hipGetLastError();
 }
 
-template <bool kLast, bool kLds, bool kFirst>
+template <bool kLast, bool kLds, bool kFirst, bool kAccel>
 static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout,
                                 int bounce, int gridBlocks, const TileMap& tile, const EyeParams& eye) {
     const size_t lds = bounceLdsBytes(layout, kLds);
-    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
+    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst, kAccel>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
                        tile, eye);
     return hipGetLastError();
 }
@@ -1188,7 +1303,11 @@ size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
                         bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye) {
     const bool isFirst = bounce == 0;
-#define PTSS_GO(a, b, c) return launchBounceT<a, b, c>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye)
+#define PTSS_GO(a, b, c)                                                                                   \
+    do {                                                                                                   \
+        if (layout.accelSpheres) return launchBounceT<a, b, c, true>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
+        return launchBounceT<a, b, c, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);   \
+    } while (0)
     if (sceneInLds) {
         if (isFirst) { if (isLast) PTSS_GO(true, true, true); else PTSS_GO(false, true, true); }
         if (isLast) PTSS_GO(true, true, false); else PTSS_GO(false, true, false);
@@ -1206,8 +1325,8 @@ hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
 int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds) {
     const size_t lds = bounceLdsBytes(layout, sceneInLds);
     int a = 0;
-    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false>, kBlock, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false>, kBlock, lds);
+    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false>, kBlock, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false>, kBlock, lds);
     return e == hipSuccess ? a : 0;
 }
 

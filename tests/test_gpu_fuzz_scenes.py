@@ -20,7 +20,7 @@ def _set3(v, xyz):
     v.x, v.y, v.z = (float(t) for t in xyz)
 
 
-def random_scene(seed):
+def random_scene(seed, ns=None, nt=None):
     rng = np.random.default_rng(seed)
     nm = int(rng.integers(2, 9))
     mats = (Material * nm)()
@@ -40,7 +40,8 @@ def random_scene(seed):
             m.diffAvg, m.specAvg, m.refrAvg = 0.0, 0.0, 0.0        # absorbs everything
         m.roughness = float(rng.choice([0.0, 0.02, 0.3, 0.9]))
         m.flags = bytes([int(rng.choice([0, 0, 1, 2, 3]))])
-    ns, nt = int(rng.integers(0, 40)), int(rng.integers(0, 24))
+    ns0, nt0 = int(rng.integers(0, 40)), int(rng.integers(0, 24))
+    ns, nt = (ns0 if ns is None else ns), (nt0 if nt is None else nt)
     sph = (Sphere * max(ns, 1))()
     for i in range(ns):
         _set3(sph[i].position, rng.uniform(-3, 3, 3) + np.array([0, 0, -4.0]))

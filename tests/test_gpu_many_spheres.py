@@ -1,0 +1,107 @@
+"""Scenes with 64 or more spheres take the chunked sphere traversal (spatially sorted 8-sphere chunks, conservative
+chunk bounds, closest hit kept as (minimum distance, highest original index)). It must stay bit-identical to the
+oracle, which tests every sphere in the caller's order: exact ties between duplicate spheres at distant indices, large
+random scenes whose rays leave the unit-direction assumption (unnormalised vertex normals), the switch off, and a
+camera far outside the range the structure is built for (the context then falls back to the plain image)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import ptss
+from test_gpu_edge_scenes import CREAM, EMIT, GLASS, GREEN, MIRROR, RED, COOK, PHONG, FLOOR, LAMP, build
+from test_gpu_fuzz_scenes import random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(scene, w, h, bounces, ticks=2, S=1, seed=0x5EED, camera=None):
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True, samples_per_pass=S, seed=seed)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=S, seed=seed)
+    if camera is not None:
+        r.set_camera(camera)
+        o.set_camera(camera)
+    for _ in range(ticks):
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts())
+    acc = r.accumulator()
+    assert np.array_equal(acc, o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert np.array_equal(r.float_accumulator(), o.float_sum(), equal_nan=True)
+    assert r.total_ray_bounces() == o.total_ray_bounces()
+    r.close()
+    return acc
+
+
+def tie_scene():
+    """96 spheres on a grid; every grid site holds the SAME sphere two or three times with different materials, the copies
+    far apart in the array, so every primary hit is an exact tie that only the index order decides."""
+    rng = np.random.default_rng(3)
+    sites = [((-3.0 + 0.75 * (i % 9), -0.9 + 0.7 * (i // 9), -4.0 - 0.2 * (i % 3)), 0.3) for i in range(36)]
+    mats = [RED, GREEN, CREAM, MIRROR, EMIT, COOK, PHONG, GLASS]
+    spheres = []
+    for rep in range(3):
+        order = rng.permutation(len(sites)) if rep else np.arange(len(sites))
+        for i in order[: 36 if rep < 2 else 24]:
+            spheres.append((sites[i][0], sites[i][1], mats[int(rng.integers(0, len(mats)))]))
+    assert len(spheres) == 96
+    return build(spheres=spheres, triangles=FLOOR + LAMP, area=[((60, 60, 60), 2)], point=[((0, 2.5, -2), (30, 30, 30))])
+
+
+def test_exact_ties_end_on_the_highest_index_like_the_sequential_loop():
+    run_pair(tie_scene(), 96, 54, 5, ticks=3)
+
+
+@pytest.mark.parametrize("seed,ns,nt", [(7001, 64, 6), (7002, 200, 20), (7003, 333, 0), (7004, 1000, 10)])
+def test_large_random_scenes(seed, ns, nt):
+    scene, rng = random_scene(seed, ns=ns, nt=nt)
+    run_pair(scene, int(rng.integers(48, 100)), int(rng.integers(27, 60)), int(rng.integers(3, 9)), S=int(rng.choice([1, 3])), seed=seed)
+
+
+def test_switch_off_gives_the_same_image():
+    scene, _ = random_scene(7010, ns=300, nt=12)
+    on = run_pair(scene, 64, 36, 6)
+    os.environ["PTSS_SPHERE_ACCEL"] = "0"
+    try:
+        off = run_pair(scene, 64, 36, 6)
+    finally:
+        del os.environ["PTSS_SPHERE_ACCEL"]
+    assert np.array_equal(on, off)
+
+
+def test_stress_scene_at_720p_chunked_equals_unchunked():
+    """BASELINE.json configs[5]'s scene, 12 bounces, at a size where millions of rays meet the chunk bounds: the chunked
+    traversal against the same library with the structure switched off (that path is the one the oracle tests pin)."""
+    def frames():
+        r = ptss.Renderer(ptss.Scene("stress"), 1280, 720, max_iterations=12, sync_each_frame=False, samples_per_pass=2)
+        counts = []
+        for _ in range(3):
+            r.generate_frame()
+            counts.append(r.live_counts().copy())
+        out = (r.accumulator(), np.array(counts), r.total_ray_bounces())
+        r.close()
+        return out
+    on = frames()
+    os.environ["PTSS_SPHERE_ACCEL"] = "0"
+    try:
+        off = frames()
+    finally:
+        del os.environ["PTSS_SPHERE_ACCEL"]
+    assert np.array_equal(on[1], off[1]) and on[2] == off[2]
+    assert np.array_equal(on[0], off[0])
+
+
+def test_camera_outside_the_structures_range_falls_back():
+    scene, _ = random_scene(7011, ns=128, nt=8)
+    cam = ptss.default_camera()
+    cam.position.x, cam.position.z = 3e16, 5.0          # beyond 1e15: squares still finite, but outside the proven range
+    run_pair(scene, 40, 24, 4, camera=cam)
+    cam.position.x = 0.25                                # and back inside: the chunked image again
+    run_pair(scene, 40, 24, 4, camera=cam)
+
+
+def test_stress_preset_switches_and_agrees():
+    scene = ptss.Scene("stress")                         # BASELINE.json configs[5]: 1,024 spheres
+    run_pair(scene, 80, 45, 6, ticks=2, S=2)
