@@ -114,6 +114,10 @@ namespace {
 // discriminant / 4 is r_i^2 - dist_i^2 + (|d|^2 - 1)(d^.v_i)^2 <= r_i^2 - dist_i^2 + 1e-5 |v_i|^2 < -1.5e-5 |v_i|^2;
 // float32 evaluation moves it by less than 1e-6 |v_i|^2 (|v_i| > r_i here). Rays whose direction is not unit to 1e-5
 // (the reference does not renormalise blended vertex normals) visit every chunk; a NaN anywhere fails the `>`.
+// Second test, same quantities: the chunk lies BEHIND the origin iff dv > 0 and dv^2 (1 - 2 eps) > R^2 (1+m)^3 + mu vv,
+// i.e. the centre's ray parameter p = -d^.vC satisfies -p > R + m (|vC| + R). Every member then has p_i + r_i < -m |v_i|,
+// so both roots the reference computes, L p_i +- sqrt(L^2 p_i^2 - |v_i|^2 + r_i^2) with L^2 = |d|^2 in 1 +- 1e-5, are
+// below -0.0018 |p_i| — negative beyond any float32 error — and Sphere::intersectRay returns false (Primitives.h:137).
 // Requires finite, moderate geometry (|coordinate|, radius <= 1e15) so that no discriminant overflows; packScene and
 // the per-frame camera check fall back to the plain image otherwise.
 constexpr double kAccelM = 5e-3;

@@ -67,7 +67,8 @@ constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workg
 #ifndef PTSS_CHUNK
 #define PTSS_CHUNK 8
 #endif
-constexpr int kChunkSpheres = PTSS_CHUNK;   // spheres per chunk of the many-sphere traversal (4 / 8 / 16 measured)
+constexpr int kChunkSpheres = PTSS_CHUNK;
+static_assert((kChunkSpheres & (kChunkSpheres - 1)) == 0, "chunk size must be a power of two");   // spheres per chunk of the many-sphere traversal (4 / 8 / 16 measured)
 constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
 constexpr int kCountStride = 32;            // one counter per 128-B line
 constexpr int kCountWords = (kMaxBounces + 1) * kShards * kCountStride;
