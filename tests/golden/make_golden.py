@@ -11,6 +11,9 @@ Outputs (all small):
                        uint16 accumulator after 16 ticks, display RGB, per-tick live counts
   c1_default.npz       the code's literal default scene, same size: accumulator, display RGB, live counts
   small_mixed.npz      96x54 'mixed', 8 bounces, 8 ticks (config 3 materials, non-square), incl. float sums
+  small_stress.npz     64x36 'stress' (config 5's 1,024 spheres), 6 bounces, 3 ticks
+  small_mixed_s4.npz   80x45 'mixed', 8 bounces, 3 ticks at samplesPerPass = 4 (the extension: lane l of pixel g owns
+                       XORWOW subsequence 4 g + l)
 """
 import json
 import os
@@ -44,9 +47,9 @@ def hexify(o):
     return o
 
 
-def render(preset, w, h, bounces, ticks, floats=True, rad0_only=False):
+def render(preset, w, h, bounces, ticks, floats=True, rad0_only=False, S=1):
     scene = ptss.Scene(preset)
-    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=SEED)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=SEED, samples_per_pass=S)
     live = []
     rad0 = None
     for t in range(ticks):
@@ -59,11 +62,13 @@ def render(preset, w, h, bounces, ticks, floats=True, rad0_only=False):
     out = dict(accumulator=acc.astype(np.uint16), pixels=o.pixels()[:, :3].copy(),
                live_counts=np.array(live, dtype=np.uint32),
                total_ray_bounces=np.array([o.total_ray_bounces()], dtype=np.uint64),
-               meta=np.array([w, h, bounces, ticks, SEED], dtype=np.int64))
-    if floats:
+               meta=np.array([w, h, bounces, ticks, SEED, S], dtype=np.int64))
+    if floats and S == 1:
         out["radiance0_tick0"] = rad0
         if not rad0_only:
             out["float_sum"] = o.float_sum()
+    elif floats:
+        out["float_sum"] = o.float_sum()
     return out
 
 
@@ -84,6 +89,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "c1_cornell.npz"), **render("cornell", 256, 256, 4, 16, rad0_only=True))
     np.savez_compressed(os.path.join(HERE, "c1_default.npz"), **render("default", 256, 256, 4, 16, floats=False))
     np.savez_compressed(os.path.join(HERE, "small_mixed.npz"), **render("mixed", 96, 54, 8, 8))
+    np.savez_compressed(os.path.join(HERE, "small_stress.npz"), **render("stress", 64, 36, 6, 3))
+    np.savez_compressed(os.path.join(HERE, "small_mixed_s4.npz"), **render("mixed", 80, 45, 8, 3, S=4))
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

@@ -72,11 +72,13 @@ def test_other_seeds_and_many_ticks():
     r.close()
 
 
-@pytest.mark.parametrize("name,preset", [("c1_cornell", "cornell"), ("c1_default", "default"), ("small_mixed", "mixed")])
+@pytest.mark.parametrize("name,preset", [("c1_cornell", "cornell"), ("c1_default", "default"), ("small_mixed", "mixed"),
+                                         ("small_stress", "stress"), ("small_mixed_s4", "mixed")])
 def test_against_committed_golden_vectors(name, preset):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    w, h, bounces, ticks, seed = [int(x) for x in g["meta"]]
-    r = ptss.Renderer(ptss.Scene(preset), w, h, max_iterations=bounces, seed=seed, float_accumulator=True)
+    w, h, bounces, ticks, seed = [int(x) for x in g["meta"][:5]]
+    S = int(g["meta"][5]) if len(g["meta"]) > 5 else 1
+    r = ptss.Renderer(ptss.Scene(preset), w, h, max_iterations=bounces, seed=seed, float_accumulator=True, samples_per_pass=S)
     live = []
     for _ in range(ticks):
         r.generate_frame()

@@ -13,10 +13,11 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _run(preset, g, upto=None):
-    w, h, bounces, ticks, seed = [int(x) for x in g["meta"]]
+    w, h, bounces, ticks, seed = [int(x) for x in g["meta"][:5]]
+    S = int(g["meta"][5]) if len(g["meta"]) > 5 else 1
     ticks = upto or ticks
     scene = ptss.Scene(preset)
-    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=seed)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=seed, samples_per_pass=S)
     live = []
     rad0 = None
     for t in range(ticks):
@@ -60,6 +61,17 @@ def test_small_mixed_full():
     assert np.array_equal(o.accumulator(), g["accumulator"].astype(np.uint32))
     assert np.array_equal(o.float_sum(), g["float_sum"], equal_nan=True)
     assert np.array_equal(rad0, g["radiance0_tick0"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name,preset", [("small_stress", "stress"), ("small_mixed_s4", "mixed")])
+def test_many_spheres_and_sample_lanes(name, preset):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o, live, _ = _run(preset, g)
+    assert np.array_equal(live, g["live_counts"])
+    assert np.array_equal(o.accumulator(), g["accumulator"].astype(np.uint32))
+    assert np.array_equal(o.pixels()[:, :3], g["pixels"])
+    assert np.array_equal(o.float_sum(), g["float_sum"], equal_nan=True)
+    assert o.total_ray_bounces() == int(g["total_ray_bounces"][0])
 
 
 def test_oracle_semantics_ticks_reset_and_mode():
