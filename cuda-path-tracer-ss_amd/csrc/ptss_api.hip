@@ -191,6 +191,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offSphere = off;      off += sphereRows;
     L.offSphereMat = off;   off += (sphereRows + 3) / 4;
     L.offSphereOrig = off;  off += accel ? (sphereRows + 3) / 4 : 0;
+    L.offSpherePos = off;   off += accel ? (L.numSpheres + 3) / 4 : 0;
     L.offChunk = off;       off += L.numChunks;
     L.offTri = off;         off += 3 * L.numTriangles;
     L.offTriNormal = off;   off += 3 * L.numTriangles;
@@ -226,6 +227,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         blob[L.offSphere + i] = float4{sp.position.x, sp.position.y, sp.position.z, sp.radius * sp.radius};
         reinterpret_cast<int*>(&blob[L.offSphereMat])[i] = sp.materialIdx;
         if (accel) reinterpret_cast<int*>(&blob[L.offSphereOrig])[i] = order[i];
+        if (accel && i < L.numSpheres) reinterpret_cast<int*>(&blob[L.offSpherePos])[order[i]] = i;
     }
     for (int k = 0; k < L.numChunks; ++k) {  // bounding sphere of the chunk, in double, rounded outwards
         double C[3] = {0, 0, 0};

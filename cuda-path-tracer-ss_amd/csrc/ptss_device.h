@@ -60,6 +60,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #ifndef PTSS_QUANT_TABLE
 #define PTSS_QUANT_TABLE 1
 #endif
+// 1: many-sphere scenes regroup their (ray, chunk) work across the wave (closestSpheresRegrouped); 0: every lane walks its own chunks
+#ifndef PTSS_REGROUP
+#define PTSS_REGROUP 0
+#endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
 #endif
@@ -97,6 +101,7 @@ struct SceneLayout {
     int numChunks;
     int offChunk;       // numChunks x {Cx, Cy, Cz, inflated R^2}
     int offSphereOrig;  // ints: original (caller's) index of each sorted sphere — decides ties the way the reference's order does
+    int offSpherePos;   // ints: the inverse, sorted position of each original index (regrouped traversal: winner by original index)
     int offQuant;       // 65 rows: the 8-bit tone-map thresholds T[0..256] (ptquant.h), read by finishPath
     int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
     int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}

@@ -393,14 +393,140 @@ __device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLa
     return occluded;
 }
 
+#if PTSS_REGROUP
+// ---- The same traversal with the work REGROUPED across the wave. In a dense scene an incoherent ray touches 30-50 chunks
+// and the counts differ widely between lanes: walking them lane by lane keeps 34 % of the lanes busy
+// (tools/stress_counters.sh). Here every lane publishes its ray and its chunk bits in the wave's LDS area, an exclusive
+// scan of the counts numbers all (ray, chunk) pairs of the wave, and each pass hands 64 consecutive pairs to the 64 lanes:
+// lane l finds the owner of pair q by bisection over the scan, the chunk as the owner's r-th set bit, tests the chunk's
+// spheres against the OWNER's ray, and folds what it finds into the owner's slot with one 64-bit LDS minimum on the key
+// (distance bits, ~original index): minimum distance first, highest original index among equals — the order-free form
+// of the reference's sequential rule (distances are >= 0 here, so their bit patterns order like the values; -0 counts as
+// +0, all-NaN rays tie on the distance and end on the highest index, as the sequential loop does). The owner finally
+// recomputes the winner's distance with the reference's own test, so the value it keeps has the reference's bits.
+__device__ __forceinline__ uint32_t nthSetBit(uint32_t word, uint32_t r) {  // position of the r-th (0-based) set bit
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t width = 16; width >= 1; width >>= 1) {
+        const uint32_t low = (uint32_t)__builtin_popcount(word & ((1u << width) - 1u));
+        const bool up = r >= low;
+        r -= up ? low : 0u;
+        word = up ? (word >> width) : word;
+        pos += up ? width : 0u;
+    }
+    return pos;
+}
+
+__device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h,
+                                                        uint32_t* ws) {
+    const uint32_t lane = __lane_id();
+    float* rayTab = reinterpret_cast<float*>(ws);                                    // [6][64]
+    uint32_t* bitsTab = ws + 6 * 64;                                                 // [4][64]
+    uint32_t* startTab = ws + 10 * 64;                                               // [64]
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 11 * 64);  // [64]
+    const int* orig = reinterpret_cast<const int*>(sc + L.offSphereOrig);
+    const int* posOf = reinterpret_cast<const int*>(sc + L.offSpherePos);
+    const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
+    rayTab[0 * 64 + lane] = o.x;
+    rayTab[1 * 64 + lane] = o.y;
+    rayTab[2 * 64 + lane] = o.z;
+    rayTab[3 * 64 + lane] = d.x;
+    rayTab[4 * 64 + lane] = d.y;
+    rayTab[5 * 64 + lane] = d.z;
+    best[lane] = ~0ull;
+    for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
+        const ChunkBits mine = chunkBits128(sc, L, g0, o, d, unitDir, live);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bitsTab[q * 64 + lane] = mine.w[q];
+            cnt += (uint32_t)__builtin_popcount(mine.w[q]);
+        }
+        uint32_t incl = cnt;  // inclusive scan over the lanes
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t below = (uint32_t)__shfl_up((int)incl, off);
+            incl += (lane >= off) ? below : 0u;
+        }
+        startTab[lane] = incl - cnt;
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);  // wave-uniform
+        waveLdsFence();
+        for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool have = q < total;
+            uint32_t lo = 0, hi = 64;  // owner = the last lane whose start <= q (its count is then > 0)
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const bool right = startTab[mid] <= q;
+                lo = right ? mid : lo;
+                hi = right ? hi : mid;
+            }
+            const uint32_t owner = have ? lo : lane;
+            uint32_t r = have ? q - startTab[owner] : 0u;
+            uint32_t word = 0, wordIdx = 0;
+            bool found = false;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t bits = bitsTab[w * 64 + owner];
+                const uint32_t pc = (uint32_t)__builtin_popcount(bits);
+                const bool here = !found && r < pc;
+                word = here ? bits : word;
+                wordIdx = here ? (uint32_t)w : wordIdx;
+                found = found || here;
+                r -= (!found) ? pc : 0u;
+            }
+            const bool work = have && found;
+            const int chunk = g0 + (int)(32u * wordIdx + nthSetBit(word, r));
+            const int base = (work ? chunk : 0) * kChunkSpheres;
+            const vec3 ro = v3(rayTab[0 * 64 + owner], rayTab[1 * 64 + owner], rayTab[2 * 64 + owner]);
+            const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
+            uint32_t mask = 0;
+            for (int i = 0; i < kChunkSpheres; ++i) {
+                const int j = (i + chunk) & (kChunkSpheres - 1);
+                if (sphereMayHit(sc[L.offSphere + base + j], ro, rd)) mask |= 1u << j;
+            }
+            if (!work) mask = 0;
+            unsigned long long key = ~0ull;
+            while (mask != 0) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                float t;
+                if (sphereTest(sc[L.offSphere + base + j], ro, rd, ptm::inf(), t)) {
+                    const uint32_t tb = (t != t) ? 0u : asU(t + 0.0f);
+                    const unsigned long long k = ((unsigned long long)tb << 32) | (unsigned long long)(0xffffffffu - (uint32_t)orig[base + j]);
+                    key = k < key ? k : key;
+                }
+            }
+            if (key != ~0ull) atomicMin(&best[owner], key);
+        }
+        waveLdsFence();
+    }
+    const unsigned long long won = best[lane];
+    if (live && won != ~0ull) {
+        const int pos = posOf[0xffffffffu - (uint32_t)won];
+        float t;
+        (void)sphereTest(sc[L.offSphere + pos], o, d, ptm::inf(), t);  // the winner's distance, with the reference's bits
+        h.distance = t;
+        h.kind = 1;
+        h.idx = pos;
+    }
+    waveLdsFence();
+}
+#endif
+
 template <bool kPrimary, bool kAccel>
-__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live) {
+__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
     Hit h;
     h.distance = ptm::inf();
     h.kind = 0;
     h.idx = 0;
     h.w0 = h.w1 = h.w2 = 0;
+#if PTSS_REGROUP
+    if constexpr (kAccel) closestSpheresRegrouped(sc, L, o, d, live, h, ws);
+#else
     if constexpr (kAccel) closestSpheresChunked(sc, L, o, d, live, h);
+#endif
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
         uint32_t mask = 0;
@@ -793,10 +919,11 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 // block: [0..kWaves) wave survivor totals, [8] block base in the output region
 // per wave: the shadow-ray queue of one NEE round (kNeeLights lights x 64 lanes):
 //           7 float planes (lo.xyz, w_i.xyz, max distance) + 1 word (owner lane | slot-in-round << 8),
-//           then kNeeLights x 64 answer words.
+//           then kNeeLights x 64 answer BYTES.
 constexpr int kNeeLights = 2;                       // lights regrouped per round
 constexpr int kQueueCap = kNeeLights * 64;
-constexpr int kWaveLdsWords = 8 * kQueueCap + kNeeLights * 64;
+constexpr int kWaveLdsWords = 8 * kQueueCap + kNeeLights * 64 / 4;  // answers are bytes: 24,048 -> 22,512 B per workgroup
+                                                                    // with the 38-primitive scenes, i.e. 7 workgroups per CU instead of 6
 constexpr int kBlockScratchVec4 = 4;
 constexpr int kBlockLdsVec4 = kBlockScratchVec4 + (kWaves * kWaveLdsWords + 3) / 4;
 
@@ -916,7 +1043,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
     [[maybe_unused]] uint32_t* scratch = reinterpret_cast<uint32_t*>(work);  // PTSS_WAVE_COMPACT=0 variant only
     float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
     uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
-    uint32_t* wqAnswer = wqOwner + kQueueCap;  // [kNeeLights][64]
+    unsigned char* wqAnswer = reinterpret_cast<unsigned char*>(wqOwner + kQueueCap);  // [kNeeLights][64], 0 / 1
 
     const float4* sc;
     if constexpr (kSceneInLds) {
@@ -984,7 +1111,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, L, ray.o, ray.d, valid);
+        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
 #endif
         PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
@@ -1067,7 +1194,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                     wq[5 * kQueueCap + slot] = w_i.z;
                     wq[6 * kQueueCap + slot] = distance;
                     wqOwner[slot] = lane | ((uint32_t)k << 8);
-                    wqAnswer[k * 64 + lane] = 0u;
+                    wqAnswer[k * 64 + lane] = 0;
                 }
                 queued += (uint32_t)__popcll(m);
             }
@@ -1099,7 +1226,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
                 if (have && sub == 0u && (verdicts & group) != 0ull) {
                     const uint32_t ow = wqOwner[es];
-                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
+                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1;
                 }
                 e0 += 1u << chunkLog;
             }
@@ -1113,7 +1240,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 const bool occ = anyHit<kAccel>(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
                 if (have && occ) {
                     const uint32_t ow = wqOwner[es];
-                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1u;
+                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1;
                 }
             }
 #endif
@@ -1123,7 +1250,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
             for (int k = 0; k < kNeeLights; ++k) {
                 const int li = l0 + k;
                 if (li >= numLights) continue;
-                if (need[k] && wqAnswer[k * 64 + lane] == 0u) {
+                if (need[k] && wqAnswer[k * 64 + lane] == 0) {
                     const vec3 power = (li < L.numPointLights) ? xyz(sc[L.offPointLight + 2 * li + 1])
                                                                : xyz(sc[L.offAreaLight + (li - L.numPointLights)]);
                     addLambertTerm(radiance, cosL[k], power, distance2[k], mat[0]);

@@ -25,6 +25,7 @@ VARIANTS = {
     "s32": ["PTSS_SHARDS=32"],
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
+    "rg": ["PTSS_REGROUP=1"],
     "ck4": ["PTSS_CHUNK=4"],
     "ck16": ["PTSS_CHUNK=16"],
     "chist": ["PTSS_CHIST=1"],
