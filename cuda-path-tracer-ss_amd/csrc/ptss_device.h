@@ -62,7 +62,7 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #endif
 // 1: many-sphere scenes regroup their (ray, chunk) work across the wave (closestSpheresRegrouped); 0: every lane walks its own chunks
 #ifndef PTSS_REGROUP
-#define PTSS_REGROUP 0
+#define PTSS_REGROUP 1
 #endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16

@@ -25,7 +25,7 @@ VARIANTS = {
     "s32": ["PTSS_SHARDS=32"],
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
-    "rg": ["PTSS_REGROUP=1"],
+    "norg": ["PTSS_REGROUP=0"],  # many-sphere scenes: every lane walks its own chunks in the closest hit too
     "ck4": ["PTSS_CHUNK=4"],
     "ck16": ["PTSS_CHUNK=16"],
     "chist": ["PTSS_CHIST=1"],
