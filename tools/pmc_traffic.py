@@ -25,7 +25,9 @@ def avg(path, sub, counter):
     return (sum(per.values()) / len(per), len(per)) if per else (0.0, 0)
 
 
-kinds = {"first": "bounceKernel<false, true, true>", "mid": "bounceKernel<false, true, false>", "last": "bounceKernel<true, true, false>"}
+# <kLast, kSceneInLds, kFirst, kAccel>: the default bench runs the LDS path without the many-sphere structure
+kinds = {"first": "bounceKernel<false, true, true, false>", "mid": "bounceKernel<false, true, false, false>",
+         "last": "bounceKernel<true, true, false, false>"}
 out = {}
 for tag, sub in kinds.items():
     f, nf = avg(os.path.join(src, "pmc_FETCH_SIZE/p_counter_collection.csv"), sub, "FETCH_SIZE")
