@@ -189,9 +189,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.numAreaLights = (int)s.numAreaLights;
     int off = 0;
     L.offSphere = off;      off += sphereRows;
-    L.offSphereMat = off;   off += (sphereRows + 3) / 4;
-    L.offSphereOrig = off;  off += accel ? (sphereRows + 3) / 4 : 0;
-    L.offSpherePos = off;   off += accel ? (L.numSpheres + 3) / 4 : 0;
+    if (!accel) { L.offSphereMat = off; off += (sphereRows + 3) / 4; }
     L.offChunk = off;       off += L.numChunks;
     L.offTri = off;         off += 3 * L.numTriangles;
     L.offTriNormal = off;   off += 3 * L.numTriangles;
@@ -202,6 +200,14 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offQuant = off;       off += ptq::kTableFloats / 4;
     L.offPrimSphere = off;  off += accel ? 0 : L.numSpheres;  // the chunked traversal has no camera-origin shortcut
     L.offPrimTri = off;     off += 2 * L.numTriangles;
+    L.ldsVec4 = off;        // everything up to here is staged into LDS
+    if (accel) {            // cold integer tables of the many-sphere image: global memory only
+        L.offSphereMat = off;   off += (sphereRows + 3) / 4;
+        L.offSphereOrig = off;  off += (sphereRows + 3) / 4;
+        L.offSpherePos = off;   off += (L.numSpheres + 3) / 4;
+    } else {
+        L.offSphereOrig = L.offSpherePos = 0;
+    }
     L.totalVec4 = off;
     auto finite3 = [](const ptss_vec3& v) { return v.x - v.x == 0.0f && v.y - v.y == 0.0f && v.z - v.z == 0.0f; };
     L.neeSkipSafe = 1;

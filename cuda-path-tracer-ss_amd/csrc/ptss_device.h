@@ -106,6 +106,8 @@ struct SceneLayout {
     int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
     int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}
     int totalVec4;
+    int ldsVec4;        // rows [0, ldsVec4) are staged into LDS; the rest (the many-sphere integer tables: material, original
+                        // index, position — read only when a hit is accepted) stay in global memory
     int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
 };
 

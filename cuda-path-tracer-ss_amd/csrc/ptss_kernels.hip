@@ -330,8 +330,8 @@ __device__ __forceinline__ int popChunk(ChunkBits& b) {  // lowest set bit, remo
     return 32 * q + k;
 }
 
-__device__ __forceinline__ void closestSpheresChunked(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h) {
-    const int* orig = reinterpret_cast<const int*>(sc + L.offSphereOrig);
+__device__ __forceinline__ void closestSpheresChunked(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h) {
+    const int* orig = reinterpret_cast<const int*>(cold + L.offSphereOrig);  // global memory (SceneLayout::ldsVec4)
     const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
     int bestOrig = -1;
     for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
@@ -419,15 +419,15 @@ __device__ __forceinline__ uint32_t nthSetBit(uint32_t word, uint32_t r) {  // p
     return pos;
 }
 
-__device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h,
-                                                        uint32_t* ws) {
+__device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d,
+                                                        bool live, Hit& h, uint32_t* ws) {
     const uint32_t lane = __lane_id();
     float* rayTab = reinterpret_cast<float*>(ws);                                    // [6][64]
     uint32_t* bitsTab = ws + 6 * 64;                                                 // [4][64]
     uint32_t* startTab = ws + 10 * 64;                                               // [64]
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 11 * 64);  // [64]
-    const int* orig = reinterpret_cast<const int*>(sc + L.offSphereOrig);
-    const int* posOf = reinterpret_cast<const int*>(sc + L.offSpherePos);
+    const int* orig = reinterpret_cast<const int*>(cold + L.offSphereOrig);  // global memory (SceneLayout::ldsVec4)
+    const int* posOf = reinterpret_cast<const int*>(cold + L.offSpherePos);
     const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
     rayTab[0 * 64 + lane] = o.x;
     rayTab[1 * 64 + lane] = o.y;
@@ -518,16 +518,16 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
 #endif
 
 template <bool kPrimary, bool kAccel>
-__device__ __forceinline__ Hit closestHit(const float4* sc, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
+__device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
     Hit h;
     h.distance = ptm::inf();
     h.kind = 0;
     h.idx = 0;
     h.w0 = h.w1 = h.w2 = 0;
 #if PTSS_REGROUP
-    if constexpr (kAccel) closestSpheresRegrouped(sc, L, o, d, live, h, ws);
+    if constexpr (kAccel) closestSpheresRegrouped(sc, cold, L, o, d, live, h, ws);
 #else
-    if constexpr (kAccel) closestSpheresChunked(sc, L, o, d, live, h);
+    if constexpr (kAccel) closestSpheresChunked(sc, cold, L, o, d, live, h);
 #endif
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
 
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    float4* work = lds + (kSceneInLds ? L.totalVec4 : 0);
+    float4* work = lds + (kSceneInLds ? L.ldsVec4 : 0);
     [[maybe_unused]] uint32_t* scratch = reinterpret_cast<uint32_t*>(work);  // PTSS_WAVE_COMPACT=0 variant only
     float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
     uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
 
     const float4* sc;
     if constexpr (kSceneInLds) {
-        for (int k = threadIdx.x; k < L.totalVec4; k += kBlock) lds[k] = sceneBlob[k];
+        for (int k = threadIdx.x; k < L.ldsVec4; k += kBlock) lds[k] = sceneBlob[k];
         __syncthreads();
         sc = lds;
     } else {
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
+        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
 #endif
         PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
             point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
             if (h.kind == 1) {
                 normal = normalize(point - xyz(sc[L.offSphere + h.idx]));
-                materialIdx = reinterpret_cast<const int*>(sc + L.offSphereMat)[h.idx];
+                materialIdx = reinterpret_cast<const int*>((kAccel ? sceneBlob : sc) + L.offSphereMat)[h.idx];
             } else {
                 const float4* nn = sc + L.offTriNormal + 3 * h.idx;
                 normal = (xyz(nn[0]) * h.w0 + xyz(nn[1]) * h.w1) + xyz(nn[2]) * h.w2;
@@ -1437,7 +1437,7 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
 hipError_t readCandidateHist(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chist), 64); }
 #endif
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
-    return ((sceneInLds ? (size_t)layout.totalVec4 : 0) + kBlockLdsVec4) * sizeof(float4);
+    return ((sceneInLds ? (size_t)layout.ldsVec4 : 0) + kBlockLdsVec4) * sizeof(float4);
 }
 
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
