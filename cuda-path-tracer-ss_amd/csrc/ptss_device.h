@@ -64,6 +64,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #ifndef PTSS_REGROUP
 #define PTSS_REGROUP 1
 #endif
+// 1: many-sphere scenes: shadow passes walk kWarmChunks chunks per lane, then regroup the rest (anySpheresHybrid)
+#ifndef PTSS_REGROUP_SHADOW
+#define PTSS_REGROUP_SHADOW 1
+#endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
 #endif

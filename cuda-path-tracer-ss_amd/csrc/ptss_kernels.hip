@@ -282,6 +282,7 @@ struct Hit {
 // spheres are hit at exactly the same distance: the sequential `<=` rule ends on the HIGHEST index among them, so the
 // closest hit keeps (minimum distance, highest original index) — identical for the finite distances this mode is
 // restricted to.
+constexpr int kQueueCapConst = 2 * 64;  // = kQueueCap (static_assert below): segments per wave queue plane
 constexpr float kAccelMu = 5e-3f + 5e-3f * 5e-3f;   // m + m^2
 constexpr float kAccelDirEps = 1e-5f;               // | |d|^2 - 1 | up to which a direction counts as unit
 constexpr float kAccelDvScale = 1.0f + 2e-5f;       // 1 / (1 - eps) rounded up
@@ -514,6 +515,140 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
         h.idx = pos;
     }
     waveLdsFence();
+}
+#endif
+
+#if PTSS_REGROUP_SHADOW
+// ---- Shadow rays of a dense queue pass, hybrid: a blocked segment is usually blocked within its first chunks, so every
+// lane walks up to kWarmChunks of its own chunks first (cheap early exits); what is left belongs to the long walkers —
+// the segments that reach their light have to visit all 30-50 chunks — and is regrouped across the wave like the closest
+// hit's work (closestSpheresRegrouped), the merge being "set the owner's blocked flag". The tables live in the half of
+// the wave's queue planes that the current pass does not read (tab[plane] = that half of plane `plane`), which is why
+// the caller uses this only for a pass whose other half is free.
+#ifndef PTSS_WARM
+#define PTSS_WARM 8   // 2 ... 16 measured within 2 % of each other
+#endif
+constexpr int kWarmChunks = PTSS_WARM;
+
+__device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLayout& L, const float* seg, float* tab, vec3 lo,
+                                                 vec3 w_i, float distance, bool have) {
+    const uint32_t lane = __lane_id();
+    uint32_t* bits0 = reinterpret_cast<uint32_t*>(tab + 0 * kQueueCapConst);
+    uint32_t* bits1 = reinterpret_cast<uint32_t*>(tab + 1 * kQueueCapConst);
+    uint32_t* bits2 = reinterpret_cast<uint32_t*>(tab + 2 * kQueueCapConst);
+    uint32_t* bits3 = reinterpret_cast<uint32_t*>(tab + 3 * kQueueCapConst);
+    uint32_t* startTab = reinterpret_cast<uint32_t*>(tab + 4 * kQueueCapConst);
+    uint32_t* blocked = reinterpret_cast<uint32_t*>(tab + 5 * kQueueCapConst);
+    const bool unitDir = ptm::abs(dot(w_i, w_i) - 1.0f) <= kAccelDirEps;
+    bool occluded = false;
+    for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
+        ChunkBits mine = chunkBits128(sc, L, g0, lo, w_i, unitDir, have && !occluded);
+        for (int it = 0; it < kWarmChunks; ++it) {  // own walk
+            if (!waveAny(anyChunk(mine))) break;
+            if (anyChunk(mine)) {
+                const int chunk = g0 + popChunk(mine);
+                const int base = chunk * kChunkSpheres;
+                uint32_t mask = 0;
+                for (int i = 0; i < kChunkSpheres; ++i) {
+                    const int j = (i + chunk) & (kChunkSpheres - 1);
+                    if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
+                }
+                while (mask != 0) {
+                    const int j = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    float t;
+                    if (sphereTest(sc[L.offSphere + base + j], lo, w_i, distance, t)) {
+                        occluded = true;
+                        mask = 0;
+                        mine.w[0] = mine.w[1] = mine.w[2] = mine.w[3] = 0u;
+                    }
+                }
+            }
+        }
+        if (!waveAny(anyChunk(mine))) continue;
+        // the rest, regrouped
+        bits0[lane] = mine.w[0];
+        bits1[lane] = mine.w[1];
+        bits2[lane] = mine.w[2];
+        bits3[lane] = mine.w[3];
+        blocked[lane] = occluded ? 1u : 0u;
+        const uint32_t cnt = (uint32_t)(__builtin_popcount(mine.w[0]) + __builtin_popcount(mine.w[1]) + __builtin_popcount(mine.w[2]) +
+                                        __builtin_popcount(mine.w[3]));
+        uint32_t incl = cnt;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t below = (uint32_t)__shfl_up((int)incl, off);
+            incl += (lane >= off) ? below : 0u;
+        }
+        startTab[lane] = incl - cnt;
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        waveLdsFence();
+        for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool valid = q < total;
+            uint32_t a = 0, b = 64;
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const uint32_t mid = (a + b) >> 1;
+                const bool right = startTab[mid] <= q;
+                a = right ? mid : a;
+                b = right ? b : mid;
+            }
+            const uint32_t owner = valid ? a : lane;
+            uint32_t r = valid ? q - startTab[owner] : 0u;
+            uint32_t word = 0, wordIdx = 0;
+            bool found = false;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t bits = (w == 0 ? bits0 : (w == 1 ? bits1 : (w == 2 ? bits2 : bits3)))[owner];
+                const uint32_t pc = (uint32_t)__builtin_popcount(bits);
+                const bool here = !found && r < pc;
+                word = here ? bits : word;
+                wordIdx = here ? (uint32_t)w : wordIdx;
+                found = found || here;
+                r -= (!found) ? pc : 0u;
+            }
+            const bool work = valid && found && blocked[owner] == 0u;
+            const int chunk = g0 + (int)(32u * wordIdx + nthSetBit(word, r));
+            const int base = (work ? chunk : 0) * kChunkSpheres;
+            const vec3 so = v3(seg[0 * kQueueCapConst + owner], seg[1 * kQueueCapConst + owner], seg[2 * kQueueCapConst + owner]);
+            const vec3 sd = v3(seg[3 * kQueueCapConst + owner], seg[4 * kQueueCapConst + owner], seg[5 * kQueueCapConst + owner]);
+            const float reach = seg[6 * kQueueCapConst + owner];
+            uint32_t mask = 0;
+            for (int i = 0; i < kChunkSpheres; ++i) {
+                const int j = (i + chunk) & (kChunkSpheres - 1);
+                if (sphereMayHit(sc[L.offSphere + base + j], so, sd)) mask |= 1u << j;
+            }
+            if (!work) mask = 0;
+            while (mask != 0) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                float t;
+                if (sphereTest(sc[L.offSphere + base + j], so, sd, reach, t)) {
+                    blocked[owner] = 1u;
+                    mask = 0;
+                }
+            }
+        }
+        waveLdsFence();
+        occluded = blocked[lane] != 0u;
+        waveLdsFence();
+    }
+    return occluded;
+}
+
+// the triangle half of lineOfSight alone (the sphere half having been answered by anySpheresHybrid)
+__device__ __forceinline__ bool anyTriangles(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, bool live) {
+    unsigned long long need = maskOf(live);
+    unsigned long long hitMask = 0ull;
+    for (int i = 0; i < L.numTriangles; ++i) {
+        if (need == 0ull) break;
+        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, need);
+        hitMask |= th.hitMask;
+        need &= ~th.hitMask;
+    }
+    return __builtin_amdgcn_inverse_ballot_w64(hitMask);
 }
 #endif
 
@@ -924,6 +1059,7 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 //           then kNeeLights x 64 answer BYTES.
 constexpr int kNeeLights = 2;                       // lights regrouped per round
 constexpr int kQueueCap = kNeeLights * 64;
+static_assert(kQueueCap == kQueueCapConst, "anySpheresHybrid's plane stride");
 constexpr int kWaveLdsWords = 8 * kQueueCap + kNeeLights * 64 / 4;  // answers are bytes: 24,048 -> 22,512 B per workgroup
                                                                     // with the 38-primitive scenes, i.e. 7 workgroups per CU instead of 6
 constexpr int kBlockScratchVec4 = 4;
@@ -1223,7 +1359,17 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
                 const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
                 const float reach = wq[6 * kQueueCap + es];
+#if PTSS_REGROUP_SHADOW
+                bool occ;
+                if (kAccel && (e0 != 0u || queued <= 64u)) {  // dense pass whose OTHER half of the queue planes is free
+                    occ = anySpheresHybrid(sc, L, wq + e0, wq + (e0 == 0u ? 64 : 0), lo, wi, reach, have);
+                    occ = occ || anyTriangles(sc, L, lo, wi, reach, have && !occ);
+                } else {
+                    occ = (shift == 0) ? anyHit<kAccel>(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+                }
+#else
                 const bool occ = (shift == 0) ? anyHit<kAccel>(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+#endif
                 const unsigned long long verdicts = __ballot(occ);  // all lanes vote before anyone branches
                 const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
                 if (have && sub == 0u && (verdicts & group) != 0ull) {

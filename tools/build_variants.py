@@ -25,6 +25,9 @@ VARIANTS = {
     "s32": ["PTSS_SHARDS=32"],
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
+    "norgs": ["PTSS_REGROUP_SHADOW=0"],  # many-sphere scenes: shadow rays walk all their chunks lane by lane
+    "warm2": ["PTSS_WARM=2"],
+    "warm16": ["PTSS_WARM=16"],
     "norg": ["PTSS_REGROUP=0"],  # many-sphere scenes: every lane walks its own chunks in the closest hit too
     "ck4": ["PTSS_CHUNK=4"],
     "ck16": ["PTSS_CHUNK=16"],
