@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the wavefront path-tracing hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py [--config c3] --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path = one call of the generateFrame drop-in (reference
-CudaTracer.cu:587-647): eye rays -> up to 8 x [intersect + NEE + scatter + compaction] -> accumulate,
+CudaTracer.cu:587-647): eye rays -> up to B x [intersect + NEE + scatter + compaction] -> accumulate,
 for S = --samples-per-pass independent samples per pixel (cfg.samplesPerPass; S = 1 is the reference's one
-sample per tick; the default S = 40 x 50 passes is the config's 2000 spp, and keeps every launch — and every
-shard of an 8-GPU run — wide enough to fill the chip; the image does not depend on N). Workload at every
-N: BASELINE.json configs[2]/[3] — 1920x1080, scene preset "mixed" (22 spheres + 16 triangles, Lambert /
-Phong / Cook-Torrance / glass / mirror), 8 bounces. For N > 1 the
-SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
+sample per tick). Workloads (`--config`, BASELINE.json `configs`):
+
+  c3 (default)  configs[2]/[3]: 1920x1080, preset "mixed" (22 spheres + 16 triangles, Lambert / Phong / Cook-Torrance /
+                glass / mirror), 8 bounces; default S = 40 x 50 passes = the config's 2000 spp
+  c2            configs[1]: 1280x720, preset "lambert" (the default scene's 36 primitives, every non-emissive material
+                Lambert), 8 bounces; default S = 32 x 16 passes = the config's 512 spp
+  c5            configs[4]: 3840x2160, preset "stress" (1,024 spheres + open Cornell box), 12 bounces; the config asks for
+                4096 spp on 8 GPUs — default here S = 4 x 16 passes = 64 spp of that very frame (a rate metric)
+
+For N > 1 the SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
 so total work is fixed ("strong" scaling); the integer accumulators are gathered to rank 0 with one
 RCCL gather inside the timed region.
 
 `value` counts rays the way BASELINE.md §2 defines them: one live ray processed in one bounce,
 summed over bounces and passes (device-side counter), over the wall time of the K timed steps.
-The `roofline` object prices the bounce kernel: algorithmic bytes = 152 B per ray-bounce (76 B SoA
-state read + 76 B written) / HIP-event time of the kernel, against 8 TB/s HBM.
-`cpu_baseline` times oracle/ (the CPU restatement, OpenMP) on a bounded slice of the same workload.
+`roofline` prices the bounce kernel two ways and names the binding one: `frac` = algorithmic bytes (152 B per
+ray-bounce: 76 B SoA state read + 76 B written) / HIP-event time of the kernel against 8 TB/s HBM;
+`valu.issue_frac` = wave-level VALU instructions per launch (SQ_INSTS_VALU, from the committed PMC summary
+profiles/pmc_counters.json, taken with this configuration) / (1,024 SIMDs x 2.4 GHz / 2 cycles x the launch time
+measured in THIS run). `cpu_baseline` times oracle/ (the CPU restatement, OpenMP) on a bounded slice of the same
+workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode.
 """
 import argparse
 import json
@@ -30,21 +38,37 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cuda-path-tracer-ss_amd"))
 
-WIDTH, HEIGHT, BOUNCES, PRESET, SEED = 1920, 1080, 8, "mixed", 0x5EED
+SEED = 0x5EED
 BYTES_PER_RAY_BOUNCE = 152          # BASELINE.md §3 / SURVEY.md §8(d)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2   # 1,024 SIMDs, one wave64 VALU instruction per 2 cycles, 2.4 GHz
 BAND_ROWS = 8
 
+CONFIGS = {
+    "c2": dict(index=1, width=1280, height=720, bounces=8, preset="lambert", spp=512, samples=32, steps=16,
+               what="36 primitives (20 spheres, 16 triangles), Lambert only"),
+    "c3": dict(index=2, width=1920, height=1080, bounces=8, preset="mixed", spp=2000, samples=40, steps=50,
+               what="22 spheres, 16 triangles, Lambert/Phong/Cook-Torrance/glass/mirror"),
+    "c5": dict(index=4, width=3840, height=2160, bounces=12, preset="stress", spp=4096, samples=4, steps=16,
+               what="1,024 random spheres + 12 triangles, all material classes (stream-compaction stress)"),
+}
 
-def cpu_baseline(budget_s=12.0):
-    """oracle/ (kind "port") on the same scene/resolution/bounces; a few passes, bounded by time."""
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """oracle/ (kind "port") on the same scene and bounce count; a few passes, bounded by time. The 4K / 1,024-sphere
+    frame costs minutes per pass on the host, so c5 is sampled at a quarter of the resolution in each direction."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     import ptss
-    scene = ptss.Scene(PRESET)
+    scene = ptss.Scene(cfg["preset"])
+    w, h = cfg["width"], cfg["height"]
+    scaled = ""
+    if cfg["preset"] == "stress":
+        w, h = w // 4, h // 4
+        scaled = f" (the {cfg['width']}x{cfg['height']} frame sampled at 1/4 resolution per axis: same scene, camera and bounces)"
     cores = oracle.cpu_share()   # affinity capped by the cgroup quota (16 on a 1-GPU box)
     oracle.set_threads(cores)
-    o = oracle.Oracle(scene.desc, WIDTH, HEIGHT, max_iterations=BOUNCES, seed=SEED)  # RNG init not timed
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=cfg["bounces"], seed=SEED)  # RNG init not timed
     o.generate_frame()  # warm-up pass (page-in), not timed
     r0 = o.total_ray_bounces()
     t0 = time.perf_counter()
@@ -56,19 +80,62 @@ def cpu_baseline(budget_s=12.0):
     rays = o.total_ray_bounces() - r0
     o.close()
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} passes (1 spp each) of {WIDTH}x{HEIGHT} '{PRESET}', {BOUNCES} bounces, "
+            "sample": f"{passes} passes (1 spp each) of {w}x{h} '{cfg['preset']}'{scaled}, {cfg['bounces']} bounces, "
                       f"{rays} ray-bounces in {dt:.1f} s, OpenMP over rays"}
+
+
+def pmc_counters(config, samples):
+    """Committed PMC summary (tools/pmc_counters.py, separate rocprofv3 --pmc passes) for exactly this configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    try:
+        j = json.load(open(path))
+        e = j.get(f"{config}_s{samples}")
+        if e:
+            return e, "profiles/pmc_counters.json[%s_s%d] (%s)" % (config, samples, j.get("source", "?"))
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
+def s1_leg(ptss, torch, scene, cfg, stream, passes=200, warmup=20):
+    """The reference's own mode on the same frame: one sample per pixel per generateFrame call (CudaTracer.cu:587-647)."""
+    r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
+                      sync_each_frame=False, samples_per_pass=1)
+    r.set_stream(stream.cuda_stream)
+    pix = torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(warmup):
+        r.generate_frame(pix.data_ptr())
+    torch.cuda.synchronize()
+    r0 = r.total_ray_bounces()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        r.generate_frame(pix.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rays = r.total_ray_bounces() - r0
+    r.close()
+    return round(rays / dt / 1e6, 2), round(dt / passes * 1e3, 4)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--samples-per-pass", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--samples-per-pass", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-s1-leg", action="store_true")
+    # Rehearsal switches for tests on a one-GPU box (the driver never passes them): every rank on device 0, and gloo
+    # (collectives staged through host memory) in place of RCCL.
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    samples = args.samples_per_pass if args.samples_per_pass is not None else cfg["samples"]
+    W, H, B, preset = cfg["width"], cfg["height"], cfg["bounces"], cfg["preset"]
 
     import torch
     import ptss
@@ -84,27 +151,24 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    # Rehearsal knobs (tests / one-GPU boxes only; the driver never sets them): PTSS_BENCH_ONE_GPU=1 puts every rank on
-    # device 0, PTSS_BENCH_BACKEND=gloo swaps RCCL for gloo (collectives staged through host memory).
-    backend = os.environ.get("PTSS_BENCH_BACKEND", "nccl")
-    if os.environ.get("PTSS_BENCH_ONE_GPU") == "1":
+    if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(args.backend)
 
     import tiles
-    scene = ptss.Scene(PRESET)
-    r = ptss.Renderer(scene, WIDTH, HEIGHT, max_iterations=BOUNCES, seed=SEED, device=local_rank,
+    scene = ptss.Scene(preset)
+    r = ptss.Renderer(scene, W, H, max_iterations=B, seed=SEED, device=local_rank,
                       tile_rank=rank, tile_world=world, band_rows=BAND_ROWS, sync_each_frame=False,
-                      time_kernels=not args.no_kernel_timing, samples_per_pass=args.samples_per_pass)
+                      time_kernels=not args.no_kernel_timing, samples_per_pass=samples)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     # torch owns the buffers that leave the renderer: accumulator (gathered) and display pixels
@@ -113,7 +177,7 @@ def main():
     r.bind_accumulator(acc.data_ptr())
     gather_list = None
     if world > 1:
-        sizes = [len(ptss.tile_rows(HEIGHT, BAND_ROWS, k, world)) * WIDTH for k in range(world)]
+        sizes = [len(ptss.tile_rows(H, BAND_ROWS, k, world)) * W for k in range(world)]
         maxn = max(sizes)
         send = torch.zeros((maxn, 3), dtype=torch.int32, device=coll_dev)
         if rank == 0:
@@ -134,7 +198,7 @@ def main():
     rays0 = r.total_ray_bounces()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     if dist is not None:              # the frame's one collective: accumulator tiles -> rank 0
         send[:r.local_pixels].copy_(acc)
@@ -143,9 +207,13 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if rank == 0 and dist is not None:   # untimed sanity: the gathered tiles tile the frame
-        sizes = [len(ptss.tile_rows(HEIGHT, BAND_ROWS, k, world)) * WIDTH for k in range(world)]
-        frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], WIDTH, HEIGHT, BAND_ROWS)
-        assert frame.shape == (WIDTH * HEIGHT, 3) and int(frame.max()) <= 255 * (args.steps + args.warmup) * args.samples_per_pass
+        sizes = [len(ptss.tile_rows(H, BAND_ROWS, k, world)) * W for k in range(world)]
+        frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], W, H, BAND_ROWS)
+        assert frame.shape == (W * H, 3) and int(frame.max()) <= 255 * (steps + args.warmup) * samples
+        dump = os.environ.get("PTSS_BENCH_DUMP_FRAME")   # tests only: the gathered accumulator, for comparison with one context
+        if dump:
+            import numpy as np
+            np.save(dump, frame)
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
     stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device=coll_dev)
@@ -155,60 +223,79 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, rays, kms, klaunches = float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3])
-        my_rays = float(stats[1])
-    else:
-        my_rays = float(rays)
 
     if rank == 0:
+        spp_run = steps * samples
         out = {
-            "metric": "Mrays/sec at 1920x1080, 8 bounces, 2000 spp (ray = one live ray processed in one bounce)",
+            "metric": f"Mrays/sec at {W}x{H}, {B} bounces, {spp_run} spp run (BASELINE configs[{cfg['index']}] asks {cfg['spp']} spp; "
+                      f"a rate metric; ray = one live ray processed in one bounce)",
             "value": round(rays / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {WIDTH}x{HEIGHT} '{PRESET}' preset (22 spheres, 16 triangles, "
-                                   f"Lambert/Phong/Cook-Torrance/glass/mirror), {BOUNCES} bounces, "
-                                   f"{args.steps * args.samples_per_pass} spp = {args.steps} passes x {args.samples_per_pass} "
-                                   f"sample lanes per pixel",
-                       "samples_per_pass": args.samples_per_pass,
+            "config": {"workload": f"configs[{cfg['index']}]: {W}x{H} '{preset}' preset ({cfg['what']}), {B} bounces, "
+                                   f"{spp_run} spp = {steps} passes x {samples} sample lanes per pixel",
+                       "name": args.config,
+                       "samples_per_pass": samples,
                        "sharding": f"{world} rank(s), interleaved {BAND_ROWS}-row pixel bands"
                                    + (", one RCCL gather of the uint3 accumulator" if world > 1 else ""),
                        "seed": SEED},
-            "mpaths_per_s": round(WIDTH * HEIGHT * args.steps * args.samples_per_pass / elapsed / 1e6, 2),
+            "parity": "bit-exact against this repo's CPU oracle (tests/); unpinned by the reference, which holds no fixtures "
+                      "and cannot be built here (DESIGN.md §4)",
+            "mpaths_per_s": round(W * H * spp_run / elapsed / 1e6, 2),
             "ray_bounces": int(rays),
+            "live_counts": [int(x) for x in r.live_counts()] if world == 1 else None,  # rays entering each bounce, last pass
         }
         if kms > 0:
             # per launch: algorithmic bytes of the rays one launch processes / that launch's duration;
             # averaged over every bounce-kernel launch of the timed region (all ranks)
             gbs = rays * BYTES_PER_RAY_BOUNCE / (kms * 1e-3) / 1e9
-            pmc = None
-            pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_file):
-                try:  # measured per launch on ONE GPU for one lane count: reported only for that very configuration
-                    j = json.load(open(pmc_file))
-                    if world == 1 and j.get("samples_per_pass") == args.samples_per_pass:
-                        pmc = j.get("hbm_bytes_per_launch")
-                except Exception:
-                    pmc = None
-            out["roofline"] = {
+            hbm_frac = gbs / HBM_PEAK_GBS
+            avg_launch_s = kms * 1e-3 / max(klaunches, 1)
+            roof = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc,
+                "frac": round(hbm_frac, 4), "traffic": None,
                 "kernel": "ptss::bounceKernel", "launches": int(klaunches),
-                "avg_launch_us": round(kms * 1e3 / max(klaunches, 1), 2),
+                "avg_launch_us": round(avg_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": round(rays * BYTES_PER_RAY_BOUNCE / max(klaunches, 1)),
                 "kernel_grays_per_s": round(rays / (kms * 1e-3) / 1e9, 3),
-                "note": "brute-force intersection puts this kernel on the FP32-VALU side of the ridge "
-                        "(BASELINE.md §3, DESIGN.md); HBM fraction is reported as the contract asks",
             }
+            pmc, src = pmc_counters(args.config, samples) if world == 1 else (None, None)
+            if pmc:
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = src + " — measured per launch in separate --pmc passes, not in this run"
+                insts = pmc.get("valu_insts_per_launch")
+                if insts:
+                    issue = insts / avg_launch_s / VALU_PEAK_WAVE_INSTR_PER_S
+                    roof["valu"] = {
+                        "insts_per_launch": insts, "issue_frac": round(issue, 4),
+                        "lanes_active": pmc.get("valu_lanes_active"),
+                        "insts_per_64_ray_tile": pmc.get("valu_insts_per_tile_mid_bounce"),
+                        "peak": "1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                        "source": src + "; launch time from this run",
+                        "measured_cost_per_instruction": "plain FP32/int 2.3, compare / select / SGPR-operand / 3-input integer "
+                                                         "4.3, transcendental 8.4 SIMD-cycles at 7 waves per SIMD "
+                                                         "(tools/microbench/vgpr_banks.hip): the mix this kernel issues cannot reach 2",
+                    }
+                    if issue > hbm_frac:
+                        roof["bound"] = "valu"
+            roof["note"] = ("brute-force intersection puts this kernel on the FP32-VALU side of the ridge (BASELINE.md §3, DESIGN.md §3): "
+                            "`frac`/`achieved`/`peak` are the HBM figures the contract asks for, `bound` names the higher of "
+                            "the HBM and VALU-issue fractions")
+            out["roofline"] = roof
+        if world == 1 and not args.no_s1_leg:
+            v, ms = s1_leg(ptss, torch, scene, cfg, stream)
+            out["s1_mrays_per_s"] = v
+            out["s1_ms_per_pass"] = ms
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
 
     r.close()

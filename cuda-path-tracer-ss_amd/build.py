@@ -3,7 +3,7 @@
   libptss.so        hipcc --offload-arch=gfx950   csrc/*.hip        the product (kernels + C-ABI)
   libptss_host.so   g++                            host/*.cpp        host mirror (Scene, camera, TGA, probes)
   ptss_main         hipcc (host only) + libptss    host/main.cpp     headless drop-in of the reference's main()
-  oracle/_build/liboracle.so   g++ -fopenmp        oracle/*.cpp      CPU restatement (test infrastructure only)
+(The CPU oracle — test infrastructure — has its own recipe, oracle/build.py; nothing here refers to it.)
 
 Both sides of the parity contract are compiled with -ffp-contract=off and without fast-math
 (DESIGN.md "Parity"); the CPU objects use -mfma -mavx2 so that ptm::fma is one correctly rounded
@@ -19,7 +19,6 @@ ROOT = os.path.dirname(HERE)
 INC = os.path.join(ROOT, "include")
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
-ORACLE = os.path.join(ROOT, "oracle")
 LIBDIR = os.path.join(HERE, "lib")
 
 FP_FLAGS = ["-ffp-contract=off", "-fno-fast-math"]
@@ -47,7 +46,7 @@ def _run(cmd):
 
 def _headers():
     hs = []
-    for d in (INC, CSRC, HOST, ORACLE):
+    for d in (INC, CSRC, HOST):
         if os.path.isdir(d):
             hs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
     return hs
@@ -59,16 +58,6 @@ def build_host(force=False):
     srcs = [os.path.join(HOST, f) for f in ("Scene.cpp", "HostOps.cpp", "host_capi.cpp")]
     if force or _newer(out, srcs + _headers()):
         _run(["g++"] + CPU_FLAGS + ["-shared", "-I", INC, "-I", CSRC, "-I", HOST] + srcs + ["-o", out])
-    return out
-
-
-def build_oracle(force=False):
-    outdir = os.path.join(ORACLE, "_build")
-    os.makedirs(outdir, exist_ok=True)
-    out = os.path.join(outdir, "liboracle.so")
-    srcs = [os.path.join(ORACLE, "oracle.cpp")]
-    if force or _newer(out, srcs + _headers()):
-        _run(["g++"] + CPU_FLAGS + ["-fopenmp", "-shared", "-I", INC, "-I", CSRC] + srcs + ["-o", out])
     return out
 
 
@@ -105,13 +94,13 @@ def build_mathcheck(force=False):
 
 
 def build_all(force=False):
-    return [build_host(force), build_oracle(force), build_device(force), build_main(force), build_mathcheck(force)]
+    return [build_host(force), build_device(force), build_main(force), build_mathcheck(force)]
 
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
     what = [a for a in sys.argv[1:] if not a.startswith("-")]
-    table = {"host": build_host, "oracle": build_oracle, "device": build_device, "main": build_main,
+    table = {"host": build_host, "device": build_device, "main": build_main,
              "mathcheck": build_mathcheck}
     if not what:
         build_all(force)

@@ -102,6 +102,18 @@ PTM_HD float rcp_if_above_1em7(float x) {
     return 1.0f / x;
 #endif
 }
+// The fast path alone, for a caller that has ALREADY established 2^-125 <= |x| < 2^126 for every operand whose result
+// it uses (the closest-hit triangle loop proves the upper bound once per query from |d| and the scene's largest
+// |e1| |e2|, and discards results with |x| <= 1e-7 like rcp_if_above_1em7's callers). Same three instructions, same bits.
+PTM_HD float rcp_in_range(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+#else
+    return 1.0f / x;
+#endif
+}
 PTM_HD uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 PTM_HD float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 PTM_HD float inf() { return u2f(0x7f800000u); }

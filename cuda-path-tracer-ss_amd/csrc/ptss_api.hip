@@ -85,7 +85,7 @@ struct ptss_context {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
     int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
-    int gridCap = 1792;          // workgroups per shard at most (PTSS_GRID_CAP overrides; 0 = uncapped)
+    int gridCap = 0;             // workgroups per shard at most = 16 resident rounds of this scene's bounce kernel (0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
     uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
@@ -188,7 +188,10 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.numPointLights = (int)s.numPointLights;
     L.numAreaLights = (int)s.numAreaLights;
     int off = 0;
-    L.offSphere = off;      off += sphereRows;
+    // plain image: sphere rows (and their camera-origin twins) padded to a multiple of four, zero-filled — the
+    // candidate pass fetches four rows per trip and drops the padding's bits (sphereCandidates)
+    const int sphereAlloc = accel ? sphereRows : (sphereRows + 3) / 4 * 4;
+    L.offSphere = off;      off += sphereAlloc;
     if (!accel) { L.offSphereMat = off; off += (sphereRows + 3) / 4; }
     L.offChunk = off;       off += L.numChunks;
     L.offTri = off;         off += 3 * L.numTriangles;
@@ -198,7 +201,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offPointLight = off;  off += 2 * L.numPointLights;
     L.offAreaLight = off;   off += L.numAreaLights;
     L.offQuant = off;       off += ptq::kTableFloats / 4;
-    L.offPrimSphere = off;  off += accel ? 0 : L.numSpheres;  // the chunked traversal has no camera-origin shortcut
+    L.offPrimSphere = off;  off += accel ? 0 : sphereAlloc;  // the chunked traversal has no camera-origin shortcut
     L.offPrimTri = off;     off += 2 * L.numTriangles;
     L.ldsVec4 = off;        // everything up to here is staged into LDS
     if (accel) {            // cold integer tables of the many-sphere image: global memory only
@@ -217,6 +220,14 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         if (!finite3(s.pointLights[i].power)) L.neeSkipSafe = 0;
     for (size_t i = 0; i < s.numAreaLights; ++i)
         if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
+    L.triDetBounded = 1;  // see SceneLayout::triDetBounded
+    for (size_t i = 0; i < s.numTriangles; ++i) {
+        const ptss_triangle& t = s.triangles[i];
+        const vec3 e1 = t.vertex1 - t.vertex0, e2 = t.vertex2 - t.vertex0;  // as stored below
+        const double n1 = std::sqrt((double)e1.x * e1.x + (double)e1.y * e1.y + (double)e1.z * e1.z);
+        const double n2 = std::sqrt((double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z);
+        if (!(n1 * n2 <= 0x1p100)) L.triDetBounded = 0;  // false for NaN / infinite edges as well
+    }
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
     ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));
     std::vector<int> order;
@@ -315,7 +326,6 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int 
     fb.staged = c->dStaged;
     fb.quantTable = reinterpret_cast<const float*>(c->dScene + c->layout.offQuant);
     fb.pixels = pixels;
-    fb.capacity = c->poolStride;
     fb.regionCap = c->regionCap;
     fb.numPixels = c->numPixels;
     fb.plane = c->capacity;
@@ -387,6 +397,7 @@ int ptss_default_config(ptss_render_config* cfg) {
     cfg->floatAccumulator = 0;
     cfg->timeKernels = 0;
     cfg->samplesPerPass = 1;
+    cfg->everySphereLoop = 0;
     return PTSS_OK;
 }
 
@@ -402,8 +413,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     if (spp < 1 || spp > 64) return fail(PTSS_EINVAL, "samplesPerPass must be in [1, 64]");
     if ((long long)cfg->width * cfg->height >= (1ll << 26)) return fail(PTSS_EINVAL, "frame too large (>= 2^26 pixels)");
     {
-        // Ray planes are addressed as plane * capacity + ray in 32 bits (19 planes): the rays of one pass — local pixels
-        // x sample lanes, rounded up to whole tiles per shard — must stay below 2^32 / 19 (~226 million).
+        // A ray's word inside its shard's region is addressed in 32 bits (slotWord: 19 planes per block): the rays of one
+        // pass — local pixels x sample lanes, rounded up to whole tiles per shard — must stay below 2^32 / 19 (~226
+        // million; the whole pool may be larger than 4 GB, regions are based with 64-bit arithmetic).
         long long rows = 0;
         for (int y = 0; y < cfg->height; ++y)
             if ((y / cfg->bandRows) % cfg->tileWorld == cfg->tileRank) ++rows;
@@ -462,9 +474,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         }
     }
 
-    // Scenes with many spheres get the chunked image (see accelEligible / packScene); PTSS_SPHERE_ACCEL=0 keeps the plain one
-    bool wantAccel = accelEligible(*scene);
-    if (const char* e = getenv("PTSS_SPHERE_ACCEL")) wantAccel = wantAccel && atoi(e) != 0;
+    // Scenes with many spheres get the chunked image (see accelEligible / packScene); cfg.everySphereLoop keeps the plain one
+    const bool wantAccel = accelEligible(*scene) && !cfg->everySphereLoop;
     std::vector<float4> blob, blobAlt;
     packScene(*scene, c->layout, blob, wantAccel);
     if (wantAccel) packScene(*scene, c->layoutAlt, blobAlt, false);
@@ -533,17 +544,29 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(e3);
     }
 
-    // Scene access path: staged into LDS (north_star). The scalar-load variant (wave-uniform
-    // s_load through the scalar cache) is kept for A/B runs via PTSS_SCENE_PATH=scalar; on the
-    // 38-primitive "mixed" scene it measured 16 % slower (profiles/README.md, r01).
+    // Scene access path: staged into LDS whenever the image fits (north_star); larger scenes are read in place. (On the
+    // 38-primitive "mixed" scene reading in place — wave-uniform s_load through the scalar cache — measured 16 % slower,
+    // profiles/README.md r01.)
     c->sceneInLds = sceneFitsLds;
     c->sceneInLdsAlt = sceneFitsLdsAlt;
-    if (const char* e = getenv("PTSS_SCENE_PATH")) {
-        if (!strcmp(e, "lds")) c->sceneInLds = sceneFitsLds;
-        if (!strcmp(e, "scalar")) c->sceneInLds = c->sceneInLdsAlt = false;
-    }
     c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
-    if (const char* e = getenv("PTSS_GRID_CAP")) c->gridCap = atoi(e);
+    {
+        // Launches wider than 16 resident rounds stop growing: a workgroup then walks several tiles and stages the scene
+        // into LDS once for all of them. One round = CUs x workgroups per CU of THIS scene's bounce kernel (LDS image and
+        // register budget decide: 7 for the 38-primitive scenes, 3-4 for the many-sphere image), so 16 rounds =
+        // CUs x perCU workgroups per shard (kShards = 16 shards). Measured on the mixed scene (256 x 7 = 1,792 per shard):
+        // 448: -4.6 %, 896: -1.3 %, 1,280-3,584: equal, uncapped: -2 % (profiles/README.md).
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        const int perCU = ptss::bounceOccupancyBlocksPerCU(c->layout, c->sceneInLds, wantAccel);
+        c->gridCap = prop.multiProcessorCount * (perCU > 0 ? perCU : 4) * 16 / ptss::kShards;
+#ifdef PTSS_TUNING_KNOBS   // measurement builds only (tools/build_variants.py "knobs"); the shipped library reads no environment
+        if (const char* e = getenv("PTSS_SCENE_PATH")) {
+            if (!strcmp(e, "scalar")) c->sceneInLds = c->sceneInLdsAlt = false;
+        }
+        if (const char* e = getenv("PTSS_GRID_CAP")) c->gridCap = atoi(e);
+#endif
+    }
     CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * ptss::kCountWords * sizeof(uint32_t), hipHostMallocDefault));
     for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreateWithFlags(&c->hintEvent[k], hipEventDisableTiming));
 #undef CREATE_TRY
@@ -658,10 +681,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             const unsigned long long want = tilesPerShard * ptss::kShards;
             if (want < (unsigned long long)blocks) blocks = (int)want;
         }
-        // Launches wider than 16 resident rounds (256 CUs x 7 workgroups = 1,792 per round, 1,792 per shard in all) stop
-        // growing: beyond that a workgroup walks several tiles and stages the scene into LDS once for all of them (+2 % at
-        // 16-40 samples per pass against uncapped, flat from 896 to 3,584; the cap never binds at 1080p with one sample
-        // per pass). PTSS_GRID_CAP=<workgroups per shard> overrides, 0 = no cap.
+        // launches wider than 16 resident rounds stop growing (gridCap, ptss_create)
         if (c->gridCap > 0 && c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
         EventPair ev{nullptr, nullptr};
         if (c->cfg.timeKernels) {

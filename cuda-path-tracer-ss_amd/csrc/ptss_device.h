@@ -10,13 +10,15 @@
 
 namespace ptss {
 
-// ---- ray pools: struct-of-arrays, one 4-byte plane per field ----------------------------------
-// plane p of a pool starts at pool + p * capacity. A pool is cut into kShards equal regions of
-// regionCap slots; the workgroups with blockIdx % kShards == s read and write region s only and
-// own the s-th live-ray counter, so the compaction atomics of one launch are spread over kShards
-// addresses (one address sustains only ~88 returning atomics/us on MI355X — measured: a single
-// counter was a 45 ps/ray serial floor, profiles/README.md). A region's survivors can never
-// outnumber its input, so regionCap = ceil(tiles / kShards) * kBlock always suffices.
+// ---- ray pools: struct-of-arrays in tile blocks ------------------------------------------------------------
+// A pool is cut into kShards equal regions of regionCap slots; the workgroups with blockIdx % kShards == s read and write
+// region s only and own the s-th live-ray counter, so the compaction atomics of one launch are spread over kShards
+// addresses (one address sustains only ~88 returning atomics/us on MI355X — measured: a single counter was a 45 ps/ray
+// serial floor, profiles/README.md). A region's survivors can never outnumber its input, so regionCap =
+// ceil(tiles / kShards) * kBlock always suffices. Inside a region the rays of one tile (kBlock consecutive slots) form a
+// BLOCK of kRayPlanes planes of kBlock words: word (slot, plane p) = ((slot / kBlock) * kRayPlanes + p) * kBlock +
+// slot % kBlock. Lane i of a wave touches word i of a plane — 256-B contiguous wave accesses — and a plane's offset
+// inside the block is a compile-time constant (addressing: ptss_kernels.hip, tileBlock / slotWord).
 enum RayPlane : int {
     kOx = 0, kOy, kOz,        // origin
     kDx, kDy, kDz,            // direction
@@ -68,6 +70,28 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #ifndef PTSS_REGROUP_SHADOW
 #define PTSS_REGROUP_SHADOW 1
 #endif
+// 1: sphere candidate masks four spheres per trip, verdicts shifted in through the carry (sphereCandidates)
+// (bit 0: closest hit, four per trip; bits 1/2: dense / lane-split shadow passes, four per trip — these spill; bits 3/4:
+// the same two, two per trip)
+#ifndef PTSS_SPHERE_UNROLL
+#define PTSS_SPHERE_UNROLL 25
+#endif
+// 1: scene rows of which three words are used are fetched as whole 16-byte rows (ds_read_b128) instead of 12 bytes
+// (ds_read_b96). A/B switch only: for these broadcast reads the 12-byte form is the faster one (tools/microbench/loops.hip:
+// 8.4 against 14 SIMD-cycles per wave-read — the LDS-to-VGPR return path moves bytes, and 768 are fewer than 1,024)
+#ifndef PTSS_ROW128
+#define PTSS_ROW128 0
+#endif
+// 2: the closest hit's triangle loop in its lean form (triangleHybrid: reciprocal's range guard hoisted to one test per
+// query, min3 for the three weight tests, selects instead of an exec-masked accept block); 1: the same without any
+// wave-uniform exit; 0: triangleTest as in the any-hit loops
+#ifndef PTSS_TRI_STRAIGHT
+#define PTSS_TRI_STRAIGHT 2
+#endif
+// 1: scatter evaluates the Snell / Fresnel terms only for lanes whose material reads them
+#ifndef PTSS_FRESNEL_SKIP
+#define PTSS_FRESNEL_SKIP 1
+#endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16
 #endif
@@ -113,6 +137,8 @@ struct SceneLayout {
     int ldsVec4;        // rows [0, ldsVec4) are staged into LDS; the rest (the many-sphere integer tables: material, original
                         // index, position — read only when a hit is accepted) stay in global memory
     int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
+    int triDetBounded;  // 1: every triangle has |e1| |e2| <= 2^100 (finite), so |det| = |e1 . (d x e2)| < 2^126 whenever
+                        //    |d|^2 < 2^30 — the closest-hit triangle loop may then use the reciprocal's fast path unguarded
 };
 
 struct TileMap {
@@ -141,8 +167,7 @@ struct FrameBuffers {
     const float* quantTable; // the same thresholds in global memory (flushKernel has no staged scene)
     uint32_t* staged;        // S > 1 only: this pass's sample of every stream, x | y << 8 | z << 16 (one plane per sample lane)
     ptss_uchar4* pixels;     // display buffer or nullptr
-    uint32_t capacity;       // pool plane stride = kShards * regionCap
-    uint32_t regionCap;      // slots per shard region
+    uint32_t regionCap;      // slots per shard region (a multiple of kBlock); a region is regionCap * kRayPlanes words
     uint32_t numPixels;      // local pixels
     uint32_t plane;          // numPixels rounded up to kBlock: stride of the per-pixel planes (one plane per sample lane)
     uint32_t samples;        // S = cfg.samplesPerPass: independent random streams per pixel traced per pass
@@ -163,6 +188,6 @@ hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sc
                         bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);
-int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds);
+int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool accel);
 
 }  // namespace ptss

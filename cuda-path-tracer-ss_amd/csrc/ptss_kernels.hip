@@ -38,6 +38,8 @@ __device__ __forceinline__ vec3 xyz(float4 v) { return vec3{v.x, v.y, v.z}; }
 // "does any lane of the wave say yes": a ballot compared with zero stays in scalar registers (s_and / s_cmp / s_cbranch);
 // hipcc's __any() round-trips the mask through a VGPR (v_cndmask + v_cmp) — two VALU instructions per triangle test
 __device__ __forceinline__ bool waveAny(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// "every active lane says yes" (p must be one direct compare, see maskOf)
+__device__ __forceinline__ bool waveAll(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 __device__ __forceinline__ void waveLdsFence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 struct PixelCoord {
@@ -70,45 +72,60 @@ struct RayRegs {
     bool active;
 };
 
-// PTSS_DEFER_LOADS fetches a ray's planes in the order the tile needs them, so that no plane occupies registers before
-// its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
-// throughput / pixel for the update at the end.
-__device__ __forceinline__ void loadRayGeometry(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
-    r.o = vec3{pool[kOx * cap + i], pool[kOy * cap + i], pool[kOz * cap + i]};
-    r.d = vec3{pool[kDx * cap + i], pool[kDy * cap + i], pool[kDz * cap + i]};
-    r.active = true;
+// ---- Ray pool addressing (ptss_device.h "ray pools"): a shard's region is a row of TILE BLOCKS, one per kBlock rays, each
+// holding the kRayPlanes planes of its rays back to back: word (tile t, plane p, lane w) sits at (t * kRayPlanes + p) *
+// kBlock + w. A tile of a workgroup is one block: its base is wave-uniform (scalar registers), the lane offset is
+// threadIdx.x and the plane offset a compile-time constant, so a plane access needs no vector address arithmetic at all
+// (the plane-major layout of round 1 spent a v_add_u32 + v_lshl_add_u64 per plane — 38 per tile, and both are half-rate
+// instructions on gfx950: tools/microbench/vgpr_banks.hip). Survivors are stored at region slot `slot`: block
+// slot / kBlock, lane slot % kBlock — one multiply-add per ray. Every access is still a 256-B contiguous wave transaction.
+__device__ __forceinline__ const float* tileBlock(const float* __restrict__ region, uint32_t firstSlot /* multiple of kBlock */) {
+    return region + (size_t)(firstSlot / kBlock) * (kRayPlanes * kBlock);
 }
-__device__ __forceinline__ void loadRayRng(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
-    r.rng.v[0] = asU(pool[kR0 * cap + i]);
-    r.rng.v[1] = asU(pool[kR1 * cap + i]);
-    r.rng.v[2] = asU(pool[kR2 * cap + i]);
-    r.rng.v[3] = asU(pool[kR3 * cap + i]);
-    r.rng.v[4] = asU(pool[kR4 * cap + i]);
-    r.rng.d = asU(pool[kRd * cap + i]);
-}
-__device__ __forceinline__ void loadRayRadiance(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
-    r.L0 = vec3{pool[kL0x * cap + i], pool[kL0y * cap + i], pool[kL0z * cap + i]};
-    r.T = vec3{pool[kTx * cap + i], pool[kTy * cap + i], pool[kTz * cap + i]};
-    r.pix = asU(pool[kPix * cap + i]);
-}
-__device__ __forceinline__ void loadRay(const float* __restrict__ pool, uint32_t cap, uint32_t i, RayRegs& r) {
-    loadRayGeometry(pool, cap, i, r);
-    loadRayRng(pool, cap, i, r);
-    loadRayRadiance(pool, cap, i, r);
+__device__ __forceinline__ uint32_t slotWord(uint32_t slot) {  // word offset of (slot, plane 0) inside the region
+    return (slot / kBlock) * (uint32_t)(kRayPlanes * kBlock) + (slot % kBlock);
 }
 
-__device__ __forceinline__ void storeRay(float* __restrict__ pool, uint32_t cap, uint32_t i, const RayRegs& r) {
-    pool[kOx * cap + i] = r.o.x;  pool[kOy * cap + i] = r.o.y;  pool[kOz * cap + i] = r.o.z;
-    pool[kDx * cap + i] = r.d.x;  pool[kDy * cap + i] = r.d.y;  pool[kDz * cap + i] = r.d.z;
-    pool[kL0x * cap + i] = r.L0.x; pool[kL0y * cap + i] = r.L0.y; pool[kL0z * cap + i] = r.L0.z;
-    pool[kTx * cap + i] = r.T.x;  pool[kTy * cap + i] = r.T.y;  pool[kTz * cap + i] = r.T.z;
-    pool[kPix * cap + i] = asF(r.pix);
-    pool[kR0 * cap + i] = asF(r.rng.v[0]);
-    pool[kR1 * cap + i] = asF(r.rng.v[1]);
-    pool[kR2 * cap + i] = asF(r.rng.v[2]);
-    pool[kR3 * cap + i] = asF(r.rng.v[3]);
-    pool[kR4 * cap + i] = asF(r.rng.v[4]);
-    pool[kRd * cap + i] = asF(r.rng.d);
+// PTSS_DEFER_LOADS fetches a ray's planes in the order the tile needs them, so that no plane occupies registers before
+// its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
+// throughput / pixel for the update at the end. `block` = the tile's block (wave-uniform), w = the ray's lane in it.
+__device__ __forceinline__ void loadRayGeometry(const float* __restrict__ block, uint32_t w, RayRegs& r) {
+    r.o = vec3{block[kOx * kBlock + w], block[kOy * kBlock + w], block[kOz * kBlock + w]};
+    r.d = vec3{block[kDx * kBlock + w], block[kDy * kBlock + w], block[kDz * kBlock + w]};
+    r.active = true;
+}
+__device__ __forceinline__ void loadRayRng(const float* __restrict__ block, uint32_t w, RayRegs& r) {
+    r.rng.v[0] = asU(block[kR0 * kBlock + w]);
+    r.rng.v[1] = asU(block[kR1 * kBlock + w]);
+    r.rng.v[2] = asU(block[kR2 * kBlock + w]);
+    r.rng.v[3] = asU(block[kR3 * kBlock + w]);
+    r.rng.v[4] = asU(block[kR4 * kBlock + w]);
+    r.rng.d = asU(block[kRd * kBlock + w]);
+}
+__device__ __forceinline__ void loadRayRadiance(const float* __restrict__ block, uint32_t w, RayRegs& r) {
+    r.L0 = vec3{block[kL0x * kBlock + w], block[kL0y * kBlock + w], block[kL0z * kBlock + w]};
+    r.T = vec3{block[kTx * kBlock + w], block[kTy * kBlock + w], block[kTz * kBlock + w]};
+    r.pix = asU(block[kPix * kBlock + w]);
+}
+__device__ __forceinline__ void loadRay(const float* __restrict__ block, uint32_t w, RayRegs& r) {
+    loadRayGeometry(block, w, r);
+    loadRayRng(block, w, r);
+    loadRayRadiance(block, w, r);
+}
+
+// `at` = region + slotWord(slot): the ray's word in plane 0 of its block
+__device__ __forceinline__ void storeRay(float* __restrict__ at, const RayRegs& r) {
+    at[kOx * kBlock] = r.o.x;  at[kOy * kBlock] = r.o.y;  at[kOz * kBlock] = r.o.z;
+    at[kDx * kBlock] = r.d.x;  at[kDy * kBlock] = r.d.y;  at[kDz * kBlock] = r.d.z;
+    at[kL0x * kBlock] = r.L0.x; at[kL0y * kBlock] = r.L0.y; at[kL0z * kBlock] = r.L0.z;
+    at[kTx * kBlock] = r.T.x;  at[kTy * kBlock] = r.T.y;  at[kTz * kBlock] = r.T.z;
+    at[kPix * kBlock] = asF(r.pix);
+    at[kR0 * kBlock] = asF(r.rng.v[0]);
+    at[kR1 * kBlock] = asF(r.rng.v[1]);
+    at[kR2 * kBlock] = asF(r.rng.v[2]);
+    at[kR3 * kBlock] = asF(r.rng.v[3]);
+    at[kR4 * kBlock] = asF(r.rng.v[4]);
+    at[kRd * kBlock] = asF(r.rng.d);
 }
 
 // ---- Sphere::intersectRay, Primitives.h:107-175. sp = {centre, radius^2}. ---------------------
@@ -160,7 +177,21 @@ struct TriHit {
 struct TriRows {  // one staged triangle: {v0, bits(materialIdx)}, {e1, 0}, {e2, 0}
     float4 a, b, c;
 };
-__device__ __forceinline__ TriRows loadTri(const float4* tr) { return TriRows{tr[0], tr[1], tr[2]}; }
+// The tests use three of a row's four words, and left alone hipcc narrows each fetch to ds_read_b96 — which the LDS
+// serves 8 lanes per cycle (8 cycles per wave-instruction, 96 B/clk/CU) against 16 lanes per cycle for ds_read_b128
+// (4 cycles; MI355X_MICROARCH.md, LDS table). Three rows per triangle, every triangle, every query: the 16-byte form
+// halves the LDS time of the triangle loops. The empty asm statement "uses" the fourth word (no instruction is
+// emitted), so the fetch cannot be narrowed.
+__device__ __forceinline__ float4 loadRow16(const float4* p) {
+    const float4 v = *p;
+#if PTSS_ROW128
+    asm volatile("" ::"v"(v.w));
+#endif
+    return v;
+}
+__device__ __forceinline__ TriRows loadTri(const float4* tr) { return TriRows{loadRow16(tr), loadRow16(tr + 1), loadRow16(tr + 2)}; }
+// the camera-origin test (triangleTestPrimary) never looks at v0
+__device__ __forceinline__ TriRows loadTriEdges(const float4* tr) { return TriRows{float4{0, 0, 0, 0}, loadRow16(tr + 1), loadRow16(tr + 2)}; }
 
 #if PTSS_TRI_GUARD2  // A/B: the general reciprocal (two range compares)
 __device__ __forceinline__ float triRcp(float det) { return ptm::rcp(det); }
@@ -201,6 +232,58 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     return h;
 }
 
+// ---- The closest hit's triangle loop, lean form (PTSS_TRI_STRAIGHT; triangleTest stays for the any-hit loops and as the
+// fallback). Same operations on the same values as triangleTest for every lane whose result is used; what changes:
+//   * The reciprocal's range guard moves out of the loop: |det| = |e1 . (d x e2)| <= |e1| |e2| |d| (1 + 4 ulp); the host
+//     bounds |e1| |e2| <= 2^100 (SceneLayout::triDetBounded) and the caller tests |d|^2 < 2^30 once per query, so
+//     |det| < 2^126; below, results with |det| <= 1e-7 are discarded (Primitives.h:41) — exactly the operand range on which
+//     ptm::rcp's fast path is proven equal to 1.0f / x. Queries that fail the test take the guarded loop.
+//   * `b0 < 0 || b1 < 0 || b2 < 0` is decided as min3(b0, b1, b2) < 0: v_min3_f32 passes over NaN operands (a NaN weight
+//     fails `< 0` in the reference too) and returns NaN only when all three are NaN (again no rejection); -0 is not < 0
+//     either way.
+//   * Only (distance, index, w1, w2) of the best hit travel through the loop, merged with selects (no exec-masked accept
+//     block); w0 = 1 - (w1 + w2) is recomputed from the kept pair by the caller — the same operation on the same values.
+//   * kExit = 2 keeps triangleTest's ONE wave-uniform exit (after the distance test): tiles of the early bounces are
+//     coherent — neighbouring pixels — and then whole waves do reject a triangle early. kExit = 1 (no exit at all) is the
+//     faster loop on incoherent rays (tools/microbench/loops.hip: 157 -> 138 SIMD-cycles per triangle per wave) and the
+//     slower kernel (same-box A/B: -1.6 %); A/B switch only.
+struct TriBest {
+    float dist;  // the running `distance` (Primitives.h:52), shared with the sphere phase
+    int idx;     // -1: no triangle accepted
+    float w1, w2;
+};
+template <bool kPrimary, bool kExit>
+__device__ __forceinline__ void triangleHybrid(const TriRows& tr, float4 ps, float4 pr, int i, vec3 o, vec3 d, unsigned long long liveMask,
+                                               TriBest& best) {
+    const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
+    const vec3 q = cross(d, e2);
+    const float det = dot(e1, q);
+    const float inverseDet = ptm::rcp_in_range(det);
+    vec3 s, r;
+    float e2r;
+    if constexpr (kPrimary) {
+        s = xyz(ps);
+        r = xyz(pr);
+        e2r = ps.w;
+    } else {
+        s = o - xyz(tr.a);
+        r = cross(s, e1);
+        e2r = dot(e2, r);
+    }
+    const float dist = e2r * inverseDet;
+    const unsigned long long passMask = liveMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > best.dist));
+    if (!kExit || passMask != 0ull) {
+        const float b1 = dot(s, q) * inverseDet;
+        const float b2 = dot(d, r) * inverseDet;
+        const float b0 = 1.0f - (b1 + b2);
+        const unsigned long long hitMask = passMask & maskOf(!(__builtin_fminf(__builtin_fminf(b0, b1), b2) < 0));
+        const bool hit = __builtin_amdgcn_inverse_ballot_w64(hitMask);
+        best.dist = hit ? dist : best.dist;
+        best.idx = hit ? i : best.idx;
+        best.w1 = hit ? b1 : best.w1;
+        best.w2 = hit ? b2 : best.w2;
+    }
+}
 // ---- Primary (bounce 0) variants. Every eye ray starts at camera.position, so whatever the tests
 // compute from the ORIGIN and the primitive alone is the same for all lanes and all pixels of a frame:
 //   sphere:   v = o - centre,  c = dot(v,v) - r^2                    (Primitives.h:109,113)
@@ -258,6 +341,92 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
     }
     return h;
 }
+
+// ---- sphere candidate masks, CudaTracer.cu:127-133 / :438-444 through Primitives.h:107-118 -------------------------
+// bit j of the result = "sphere j of this block of up to 32 passes the reference's discriminant test" — the very
+// operations of sphereMayHit, four spheres per trip: the four rows are fetched with one address and immediate offsets
+// (the host pads the sphere rows to a multiple of four, packScene; a padding row's bit is dropped by the caller's `keep`
+// mask), and each verdict enters the mask through the carry of one add (mask = 2 * mask + verdict: v_cmp + v_addc
+// instead of v_cmp + v_cndmask + v_or and a v_mov for the bit). That leaves the first sphere in the highest bit; one
+// v_bfrev + shift puts sphere j at bit j, which the candidate loops need (they walk in index order).
+// rev = 2 * rev + !(disc < 0) for one sphere, disc = b * b - 4 * c (Primitives.h:115-118). `disc < 0` is decided as
+// `b * b < 4 * c`: a correctly rounded difference of two floats is negative exactly when the first is the smaller
+// (gradual underflow: it is zero only for equal operands; inf - inf = NaN and a NaN operand make both forms false) —
+// hipcc performs the same fold on its own. The verdict goes from VCC into the mask as the carry of one add.
+__device__ __forceinline__ void shiftInMayHit(uint32_t& rev, float bb, float c4) {
+    asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rev) : "v"(bb), "v"(c4) : "vcc");
+}
+__device__ __forceinline__ void shiftInSphere(uint32_t& rev, float4 sp, vec3 o, vec3 d) {  // sphereMayHit's operations
+    const vec3 v = o - xyz(sp);
+    const float b = dot(d, v) * 2;
+    const float c = dot(v, v) - sp.w;
+    shiftInMayHit(rev, b * b, 4 * c);
+}
+__device__ __forceinline__ void shiftInSpherePrimary(uint32_t& rev, float4 pv, vec3 d) {  // sphereMayHitPrimary's
+    const float b = dot(d, xyz(pv)) * 2;
+    shiftInMayHit(rev, b * b, 4 * pv.w);
+}
+template <bool kPrimary>
+__device__ __forceinline__ uint32_t sphereCandidates(const float4* rows, int cnt, vec3 o, vec3 d) {
+    const int trips = (cnt + 3) >> 2;  // wave-uniform, 1..8
+    uint32_t rev = 0;
+    for (int g = 0; g < trips; ++g) {
+        const float4 r0 = rows[4 * g], r1 = rows[4 * g + 1], r2 = rows[4 * g + 2], r3 = rows[4 * g + 3];
+        if constexpr (kPrimary) {
+            shiftInSpherePrimary(rev, r0, d);
+            shiftInSpherePrimary(rev, r1, d);
+            shiftInSpherePrimary(rev, r2, d);
+            shiftInSpherePrimary(rev, r3, d);
+        } else {
+            shiftInSphere(rev, r0, o, d);
+            shiftInSphere(rev, r1, o, d);
+            shiftInSphere(rev, r2, o, d);
+            shiftInSphere(rev, r3, o, d);
+        }
+    }
+    return __builtin_bitreverse32(rev) >> (32 - 4 * trips);
+}
+// two spheres per trip: for the shadow passes, where the registers are needed elsewhere (four rows in flight there
+// push the 72-VGPR kernel into scratch)
+__device__ __forceinline__ uint32_t sphereCandidatesPairs(const float4* rows, int cnt, vec3 o, vec3 d) {
+    const int trips = (cnt + 1) >> 1;  // 1..16
+    uint32_t rev = 0;
+    for (int g = 0; g < trips; ++g) {
+        const float4 r0 = rows[2 * g], r1 = rows[2 * g + 1];
+        shiftInSphere(rev, r0, o, d);
+        shiftInSphere(rev, r1, o, d);
+    }
+    return __builtin_bitreverse32(rev) >> (32 - 2 * trips);
+}
+__device__ __forceinline__ uint32_t sphereCandidatesStridedPairs(const float4* first, int stride, int cnt, vec3 o, vec3 d) {
+    const int trips = (cnt + 1) >> 1;
+    uint32_t rev = 0;
+    for (int g = 0; g < trips; ++g) {
+        const float4* p = first + 2 * g * stride;
+        const float4 r0 = p[0], r1 = p[stride];
+        shiftInSphere(rev, r0, o, d);
+        shiftInSphere(rev, r1, o, d);
+    }
+    return __builtin_bitreverse32(rev) >> (32 - 2 * trips);
+}
+__device__ __forceinline__ uint32_t lowBits(int cnt) { return (cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u); }
+// the same for a lane that visits every `stride`-th sphere starting at its own `first` row (anyHitSplit). Rows past the
+// scene's last sphere may be read (at most 31 of them: other rows of the scene image, which always ends in the 65-row
+// tone-map table); their bits are dropped by the caller.
+__device__ __forceinline__ uint32_t sphereCandidatesStrided(const float4* first, int stride, int cnt, vec3 o, vec3 d) {
+    const int trips = (cnt + 3) >> 2;
+    uint32_t rev = 0;
+    for (int g = 0; g < trips; ++g) {
+        const float4* p = first + 4 * g * stride;
+        const float4 r0 = p[0], r1 = p[stride], r2 = p[2 * stride], r3 = p[3 * stride];
+        shiftInSphere(rev, r0, o, d);
+        shiftInSphere(rev, r1, o, d);
+        shiftInSphere(rev, r2, o, d);
+        shiftInSphere(rev, r3, o, d);
+    }
+    return __builtin_bitreverse32(rev) >> (32 - 4 * trips);
+}
+__device__ __forceinline__ uint32_t lowBitsClamped(int cnt) { return (cnt <= 0) ? 0u : lowBits(cnt); }
 
 // ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
 // Spheres, 32 at a time: a uniform pass records in a per-lane bit mask which spheres survive the
@@ -666,6 +835,10 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
 #endif
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
+#if PTSS_SPHERE_UNROLL & 1
+        uint32_t mask = sphereCandidates<kPrimary>(sc + (kPrimary ? L.offPrimSphere : L.offSphere) + base, cnt, o, d);
+        mask &= live ? lowBits(cnt) : 0u;
+#else
         uint32_t mask = 0;
         for (int j = 0; j < cnt; ++j) {
             const bool may = kPrimary ? sphereMayHitPrimary(sc[L.offPrimSphere + base + j], d)
@@ -673,6 +846,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
             if (may) mask |= 1u << j;
         }
         if (!live) mask = 0;
+#endif
 #ifdef PTSS_CHIST  // diagnostic: sphere candidates per lane, wave maximum vs wave mean (tools/candidate_hist.py)
         {
             const uint32_t pc = (uint32_t)__builtin_popcount(mask);
@@ -702,9 +876,33 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
         }
     }
     const unsigned long long liveMask = maskOf(live);
+#if PTSS_TRI_STRAIGHT
+    // one test per query instead of one per triangle: |d|^2 < 2^30 in every lane (false for a NaN direction)
+    if (L.triDetBounded && waveAll(dot(d, d) < 0x1p30f)) {
+        TriBest best{h.distance, -1, 0.0f, 0.0f};
+        for (int i = 0; i < L.numTriangles; ++i) {
+            const TriRows tcur = kPrimary ? loadTriEdges(sc + L.offTri + 3 * i) : loadTri(sc + L.offTri + 3 * i);
+            float4 ps = float4{0, 0, 0, 0}, pr = ps;
+            if constexpr (kPrimary) {
+                ps = sc[L.offPrimTri + 2 * i];
+                pr = loadRow16(sc + L.offPrimTri + 2 * i + 1);
+            }
+            triangleHybrid<kPrimary, PTSS_TRI_STRAIGHT == 2>(tcur, ps, pr, i, o, d, liveMask, best);
+        }
+        if (best.idx >= 0) {
+            h.distance = best.dist;
+            h.kind = 2;
+            h.idx = best.idx;
+            h.w1 = best.w1;
+            h.w2 = best.w2;
+            h.w0 = 1.0f - (best.w1 + best.w2);  // Primitives.h:64, from the kept pair
+        }
+        return h;
+    }
+#endif
     for (int i = 0; i < L.numTriangles; ++i) {
-        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
-        const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], sc[L.offPrimTri + 2 * i + 1], d,
+        const TriRows tcur = kPrimary ? loadTriEdges(sc + L.offTri + 3 * i) : loadTri(sc + L.offTri + 3 * i);
+        const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], loadRow16(sc + L.offPrimTri + 2 * i + 1), d,
                                                          h.distance, liveMask)
                                    : triangleTest(tcur, o, d, h.distance, liveMask);
         if (th.hit) {
@@ -729,10 +927,18 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
     if constexpr (kAccel) occluded = anySphereChunked(sc, L, lo, w_i, distance, live);
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
+#if PTSS_SPHERE_UNROLL & 8
+        uint32_t mask = sphereCandidatesPairs(sc + L.offSphere + base, cnt, lo, w_i);
+        mask &= (live && !occluded) ? lowBits(cnt) : 0u;
+#elif PTSS_SPHERE_UNROLL & 2
+        uint32_t mask = sphereCandidates<false>(sc + L.offSphere + base, cnt, lo, w_i);
+        mask &= (live && !occluded) ? lowBits(cnt) : 0u;
+#else
         uint32_t mask = 0;
         for (int j = 0; j < cnt; ++j)
             if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
         if (!live || occluded) mask = 0;
+#endif
 #ifdef PTSS_CHIST
         {
             const uint32_t pc = (uint32_t)__builtin_popcount(mask);
@@ -782,6 +988,14 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
     const int sphereSteps = (L.numSpheres + g - 1) >> shift;
     for (int base = 0; base < sphereSteps; base += 32) {
         const int cnt = (sphereSteps - base < 32) ? (sphereSteps - base) : 32;
+#if PTSS_SPHERE_UNROLL & 16
+        uint32_t mask = sphereCandidatesStridedPairs(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
+        mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
+#elif PTSS_SPHERE_UNROLL & 4
+        uint32_t mask = sphereCandidatesStrided(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
+        // this lane's spheres are sub, sub + g, ...: step j exists for it iff (j << shift) + sub < numSpheres
+        mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
+#else
         uint32_t mask = 0;
         for (int j = 0; j < cnt; ++j) {
             const int idx = ((base + j) << shift) + sub;
@@ -789,6 +1003,7 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
             if (in && sphereMayHit(sc[L.offSphere + (in ? idx : 0)], lo, w_i)) mask |= 1u << j;
         }
         if (!live || occluded) mask = 0;
+#endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -875,12 +1090,27 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
             n1 = mMisc.y;
             n2 = 1.0f;
         }
+#if PTSS_FRESNEL_SKIP
+        // The Snell / Fresnel terms (two square roots' worth and three divisions) feed only the Fresnel-weighted specular
+        // lobe (:248-249) and the refraction lobe (:300-311). A material with the pure-reflection bit (mirrors AND every
+        // Cook-Torrance material, 0x03 & 0x01) and no refraction never reads them: its lanes skip the block, and a wave
+        // without glass skips it altogether. (cosI's flip above is kept: reflRay uses it.)
+        const bool readsFresnel = (mSpecular.w > 0.0f && !(flags & PTSS_MAT_FLAG_PURE_REFLECTION)) || refrAvg > 0.0f;
+        float n = 0.0f, sinT2 = 0.0f;
+        float fresnelReflective = 1.0f;
+        if (readsFresnel) {
+            n = ptm::div(n1, n2);
+            sinT2 = n * n * (1.0f - cosI * cosI);
+        }
+        if (readsFresnel && !(sinT2 > 1.0f)) {
+#else
         const float n = ptm::div(n1, n2);
         const float sinT2 = n * n * (1.0f - cosI * cosI);
 
         // computeFresnelForReflectance :457-472
         float fresnelReflective = 1.0f;
         if (!(sinT2 > 1.0f)) {
+#endif
             const float cosT = ptm::sqrt(1.0f - sinT2);
             const float r_s = ptm::div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
             const float r_p = ptm::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
@@ -1193,9 +1423,9 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
     }
     const float* quantT = reinterpret_cast<const float*>(sc + L.offQuant);
 
-    const uint32_t cap = fb.capacity;
-    const float* __restrict__ in = fb.pool[bounce & 1] + shard * fb.regionCap;  // this shard's region
-    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * fb.regionCap;
+    const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
+    const float* __restrict__ in = fb.pool[bounce & 1] + shard * regionWords;  // this shard's region
+    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * regionWords;
     const int numLights = L.numPointLights + L.numAreaLights;
 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
@@ -1238,9 +1468,9 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
             }
         } else {
 #if PTSS_DEFER_LOADS
-            if (valid) loadRayGeometry(in, cap, i, ray);
+            if (valid) loadRayGeometry(tileBlock(in, base), threadIdx.x, ray);
 #else
-            if (valid) loadRay(in, cap, i, ray);
+            if (valid) loadRay(tileBlock(in, base), threadIdx.x, ray);
 #endif
         }
         PTSS_STAMP(0);  // ray load / eye-ray generation
@@ -1255,7 +1485,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
         const bool hit = valid && h.kind != 0;
 #if PTSS_DEFER_LOADS
         if constexpr (!kFirst) {
-            if (valid) loadRayRng(in, cap, i, ray);
+            if (valid) loadRayRng(tileBlock(in, base), threadIdx.x, ray);
         }
 #endif
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
@@ -1264,11 +1494,11 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
         if (hit) {
             point = ray.o + ray.d * h.distance;  // Primitives.h:74, :100
             if (h.kind == 1) {
-                normal = normalize(point - xyz(sc[L.offSphere + h.idx]));
+                normal = normalize(point - xyz(loadRow16(sc + L.offSphere + h.idx)));
                 materialIdx = reinterpret_cast<const int*>((kAccel ? sceneBlob : sc) + L.offSphereMat)[h.idx];
             } else {
                 const float4* nn = sc + L.offTriNormal + 3 * h.idx;
-                normal = (xyz(nn[0]) * h.w0 + xyz(nn[1]) * h.w1) + xyz(nn[2]) * h.w2;
+                normal = (xyz(loadRow16(nn)) * h.w0 + xyz(loadRow16(nn + 1)) * h.w1) + xyz(loadRow16(nn + 2)) * h.w2;
                 materialIdx = (int)asU(sc[L.offTri + 3 * h.idx].w);
             }
             cosI = dot(-ray.d, normal);
@@ -1295,7 +1525,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 if (lit) {
                     vec3 lightPoint;
                     if (li < L.numPointLights) {
-                        lightPoint = xyz(sc[L.offPointLight + 2 * li]);
+                        lightPoint = xyz(loadRow16(sc + L.offPointLight + 2 * li));
                     } else {  // getAreaLightPoint :392-418 — four draws whether or not the light ends up visible
                         const float4 light = sc[L.offAreaLight + (li - L.numPointLights)];
                         const float u1 = ptrng::uniform(ray.rng);
@@ -1304,9 +1534,9 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                         const float inverseTotal = ptm::rcp(u1 + u2 + u3);  // 1 / (u1+u2+u3), :403
                         const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
                         const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
-                        const vec3 a = xyz(sc[L.offTri + 3 * tri]);
-                        const vec3 b = xyz(sc[L.offTriVert + 2 * tri]);
-                        const vec3 c = xyz(sc[L.offTriVert + 2 * tri + 1]);
+                        const vec3 a = xyz(loadRow16(sc + L.offTri + 3 * tri));
+                        const vec3 b = xyz(loadRow16(sc + L.offTriVert + 2 * tri));
+                        const vec3 c = xyz(loadRow16(sc + L.offTriVert + 2 * tri + 1));
                         lightPoint = (a * weight0 + b * weight1) + c * weight2;
                     }
                     // head of lineOfSight :423-432
@@ -1399,8 +1629,8 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 const int li = l0 + k;
                 if (li >= numLights) continue;
                 if (need[k] && wqAnswer[k * 64 + lane] == 0) {
-                    const vec3 power = (li < L.numPointLights) ? xyz(sc[L.offPointLight + 2 * li + 1])
-                                                               : xyz(sc[L.offAreaLight + (li - L.numPointLights)]);
+                    const vec3 power = (li < L.numPointLights) ? xyz(loadRow16(sc + L.offPointLight + 2 * li + 1))
+                                                               : xyz(loadRow16(sc + L.offAreaLight + (li - L.numPointLights)));
                     addLambertTerm(radiance, cosL[k], power, distance2[k], mat[0]);
                 }
             }
@@ -1411,7 +1641,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
         bool alive = false;
 #if PTSS_DEFER_LOADS
         if constexpr (!kFirst) {
-            if (valid) loadRayRadiance(in, cap, i, ray);
+            if (valid) loadRayRadiance(tileBlock(in, base), threadIdx.x, ray);
         }
 #endif
         if (valid) {
@@ -1455,7 +1685,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                 slot = base0;  // consumed after the finish work below
                 if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
                 slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
-                if (alive) storeRay(out, cap, slot, ray);
+                if (alive) storeRay(out + slotWord(slot), ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
                 finishPath(fb, ray, quantT);
             }
@@ -1479,7 +1709,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
             __syncthreads();
             uint32_t slot = scratch[8] + rank;
             for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
-            if (alive) storeRay(out, cap, slot, ray);
+            if (alive) storeRay(out + slotWord(slot), ray);
             __syncthreads();  // scratch is rewritten by the next tile
         }
 #endif
@@ -1528,7 +1758,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
             const uint32_t n = fb.counts[countIndex(stop, s)];
             if (i < n) {
                 RayRegs ray;
-                loadRay(fb.pool[stop & 1] + s * fb.regionCap, fb.capacity, i, ray);
+                loadRay(tileBlock(fb.pool[stop & 1] + (size_t)s * fb.regionCap * kRayPlanes, (i / kBlock) * kBlock), i % kBlock, ray);
                 finishPath(fb, ray, fb.quantTable);
             }
         }
@@ -1608,11 +1838,17 @@ hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
     return hipGetLastError();
 }
 
-int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds) {
+// Resident workgroups per CU of the mid-bounce instantiation that `layout` runs (registers and this scene's LDS image)
+int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool accel) {
     const size_t lds = bounceLdsBytes(layout, sceneInLds);
     int a = 0;
-    hipError_t e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false>, kBlock, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false>, kBlock, lds);
+    hipError_t e;
+    if (accel)
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, true>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, true>, kBlock, lds);
+    else
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false>, kBlock, lds);
     return e == hipSuccess ? a : 0;
 }
 

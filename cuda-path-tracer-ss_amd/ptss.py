@@ -32,7 +32,7 @@ class RenderConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("seed", C.c_ulonglong), ("maxIterations", C.c_uint),
                 ("device", C.c_int), ("tileRank", C.c_int), ("tileWorld", C.c_int), ("bandRows", C.c_int),
                 ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int),
-                ("samplesPerPass", C.c_int)]
+                ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int)]
 
 
 _host = None
@@ -197,7 +197,8 @@ class Renderer:
     """One ptss_context: the reference's ProgramData + device buffers, driven like generateFrame."""
 
     def __init__(self, scene, width, height, max_iterations=15, seed=0x5EED, device=0, tile_rank=0, tile_world=1,
-                 band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1):
+                 band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1,
+                 every_sphere_loop=False):
         L = device_lib()
         cfg = RenderConfig()
         _check(L.ptss_default_config(C.byref(cfg)))
@@ -210,6 +211,7 @@ class Renderer:
         cfg.floatAccumulator = 1 if float_accumulator else 0
         cfg.timeKernels = 1 if time_kernels else 0
         cfg.samplesPerPass = samples_per_pass
+        cfg.everySphereLoop = 1 if every_sphere_loop else 0
         self.cfg = cfg
         self._scene = scene  # keep the arrays alive during create
         self._ctx = C.c_void_p()

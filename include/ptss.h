@@ -44,6 +44,9 @@ typedef struct ptss_render_config {
      * is still tone-mapped on its own before it is summed (CudaTracer.cu:72-92); the display divides by
      * S*(ticks - lastResetTick + 1). Lets one launch carry S times the rays (multi-GPU shards stay busy). 1..64. */
     int samplesPerPass;
+    /* Scenes with >= 64 finite spheres are traversed through spatially sorted sphere chunks (same image
+     * as the reference's every-sphere loop, tests/test_gpu_many_spheres.py). 1 keeps the every-sphere loop for them too. */
+    int everySphereLoop;
 } ptss_render_config;
 
 /* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */

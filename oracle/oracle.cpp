@@ -40,7 +40,11 @@
 #include <algorithm>
 #include <vector>
 
+#ifdef ORACLE_LIBM_MATH   // second build, sharing no arithmetic with the product: oracle/libm_math.h
+#include "libm_math.h"
+#else
 #include "ptmath.h"
+#endif
 #include "ptss_types.h"
 
 using namespace ptv;

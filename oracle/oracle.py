@@ -17,17 +17,18 @@ if _PKG not in sys.path:
 from ptss_types import Camera, SceneDesc, Sphere, Triangle  # noqa: E402  (layouts only, no product code)
 
 LIB = os.path.join(_HERE, "_build", "liboracle.so")
+LIB_LIBM = os.path.join(_HERE, "_build", "liboracle_libm.so")  # the same source against libm (oracle/libm_math.h)
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} missing: run `python __graft_entry__.py build`")
-        L = C.CDLL(LIB)
+def lib(path=None):
+    path = path or LIB
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python __graft_entry__.py build`")
+        L = C.CDLL(path)
         vp = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int, C.c_int]
         L.oracle_create.restype = vp
@@ -72,8 +73,8 @@ def lib():
         L.oracle_probe_rng.restype = None
         L.oracle_probe_eye_ray.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera), C.c_ulonglong, _f32p]
         L.oracle_probe_eye_ray.restype = None
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def set_threads(n):
@@ -104,10 +105,12 @@ class Oracle:
     """CPU generateFrame over a full frame. scene_desc: a ptss_types.SceneDesc (kept alive by the caller)."""
 
     def __init__(self, scene_desc, width, height, max_iterations=15, seed=0x5EED, literal_slot_rng=False,
-                 samples_per_pass=1):
+                 samples_per_pass=1, math="ptmath"):
+        """math="ptmath": the bit-exact checker (shares csrc/ptmath.h with the kernels); "libm": the independent build."""
         self.width, self.height = width, height
         self.n = width * height
-        self._c = lib().oracle_create(C.byref(scene_desc), width, height, seed, max_iterations,
+        self._L = lib(LIB_LIBM if math == "libm" else LIB)
+        self._c = self._L.oracle_create(C.byref(scene_desc), width, height, seed, max_iterations,
                                       1 if literal_slot_rng else 0, samples_per_pass)
         if not self._c:
             raise RuntimeError("oracle_create failed")
@@ -116,7 +119,7 @@ class Oracle:
 
     def close(self):
         if self._c:
-            lib().oracle_destroy(self._c)
+            self._L.oracle_destroy(self._c)
             self._c = None
 
     def __del__(self):
@@ -129,48 +132,48 @@ class Oracle:
         if ticks is None:
             ticks = self.ticks
             self.ticks += 1
-        lib().oracle_generate_frame(self._c, self.pixels_host.ctypes.data_as(C.c_void_p), ticks)
+        self._L.oracle_generate_frame(self._c, self.pixels_host.ctypes.data_as(C.c_void_p), ticks)
 
     def set_camera(self, cam):
-        lib().oracle_set_camera(self._c, C.byref(cam))
+        self._L.oracle_set_camera(self._c, C.byref(cam))
 
     def set_mode(self, use_path_tracer):
-        lib().oracle_set_mode(self._c, 1 if use_path_tracer else 0)
+        self._L.oracle_set_mode(self._c, 1 if use_path_tracer else 0)
 
     def set_max_iterations(self, n):
-        lib().oracle_set_max_iterations(self._c, n)
+        self._L.oracle_set_max_iterations(self._c, n)
 
     def request_reset(self):
-        lib().oracle_request_reset(self._c)
+        self._L.oracle_request_reset(self._c)
 
     def accumulator(self):
-        return np.ctypeslib.as_array(lib().oracle_accumulator(self._c), shape=(self.n, 3)).copy()
+        return np.ctypeslib.as_array(self._L.oracle_accumulator(self._c), shape=(self.n, 3)).copy()
 
     def float_sum(self):
-        return np.ctypeslib.as_array(lib().oracle_float_sum(self._c), shape=(self.n, 3)).copy()
+        return np.ctypeslib.as_array(self._L.oracle_float_sum(self._c), shape=(self.n, 3)).copy()
 
     def last_radiance0(self):
-        return np.ctypeslib.as_array(lib().oracle_last_radiance0(self._c), shape=(self.n, 3)).copy()
+        return np.ctypeslib.as_array(self._L.oracle_last_radiance0(self._c), shape=(self.n, 3)).copy()
 
     def pixels(self):
         return self.pixels_host.copy()
 
     def live_counts(self):
         buf = (C.c_uint32 * 65)()
-        n = lib().oracle_live_counts(self._c, buf, 65)
+        n = self._L.oracle_live_counts(self._c, buf, 65)
         return np.array(buf[:n], dtype=np.uint32)
 
     def total_ray_bounces(self):
-        return int(lib().oracle_total_ray_bounces(self._c))
+        return int(self._L.oracle_total_ray_bounces(self._c))
 
     def rng_state(self, pixel, lane=0):
         out = np.empty(6, dtype=np.uint32)
-        lib().oracle_rng_state(self._c, pixel, lane, out.ctypes.data_as(_u32p))
+        self._L.oracle_rng_state(self._c, pixel, lane, out.ctypes.data_as(_u32p))
         return out
 
     def probe_shade(self, point, normal, material_idx, seed=1):
         out = (C.c_float * 3)()
-        lib().oracle_probe_shade(self._c, _f3(point), _f3(normal), material_idx, seed, out)
+        self._L.oracle_probe_shade(self._c, _f3(point), _f3(normal), material_idx, seed, out)
         return np.array(out[:], dtype=np.float32)
 
 

@@ -22,4 +22,13 @@ def _native_built():
     if missing:
         import __graft_entry__
         __graft_entry__.build()
+    # PyTorch ships its own copy of the HIP runtime and libptss.so links ROCm's: when both live in one process, torch's
+    # must initialise first (bench.py's order) — a torch.cuda call that comes after several libptss contexts have come
+    # and gone can fail with "No HIP GPUs are available". Harmless without a GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     yield

@@ -16,8 +16,9 @@ from test_gpu_fuzz_scenes import random_scene
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(scene, w, h, bounces, ticks=2, S=1, seed=0x5EED, camera=None):
-    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True, samples_per_pass=S, seed=seed)
+def run_pair(scene, w, h, bounces, ticks=2, S=1, seed=0x5EED, camera=None, every_sphere_loop=False):
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True, samples_per_pass=S, seed=seed,
+                      every_sphere_loop=every_sphere_loop)
     o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=S, seed=seed)
     if camera is not None:
         r.set_camera(camera)
@@ -63,19 +64,16 @@ def test_large_random_scenes(seed, ns, nt):
 def test_switch_off_gives_the_same_image():
     scene, _ = random_scene(7010, ns=300, nt=12)
     on = run_pair(scene, 64, 36, 6)
-    os.environ["PTSS_SPHERE_ACCEL"] = "0"
-    try:
-        off = run_pair(scene, 64, 36, 6)
-    finally:
-        del os.environ["PTSS_SPHERE_ACCEL"]
+    off = run_pair(scene, 64, 36, 6, every_sphere_loop=True)   # cfg.everySphereLoop: the reference's loop over every sphere
     assert np.array_equal(on, off)
 
 
 def test_stress_scene_at_720p_chunked_equals_unchunked():
     """BASELINE.json configs[5]'s scene, 12 bounces, at a size where millions of rays meet the chunk bounds: the chunked
     traversal against the same library with the structure switched off (that path is the one the oracle tests pin)."""
-    def frames():
-        r = ptss.Renderer(ptss.Scene("stress"), 1280, 720, max_iterations=12, sync_each_frame=False, samples_per_pass=2)
+    def frames(every_sphere_loop=False):
+        r = ptss.Renderer(ptss.Scene("stress"), 1280, 720, max_iterations=12, sync_each_frame=False, samples_per_pass=2,
+                          every_sphere_loop=every_sphere_loop)
         counts = []
         for _ in range(3):
             r.generate_frame()
@@ -84,12 +82,24 @@ def test_stress_scene_at_720p_chunked_equals_unchunked():
         r.close()
         return out
     on = frames()
-    os.environ["PTSS_SPHERE_ACCEL"] = "0"
-    try:
-        off = frames()
-    finally:
-        del os.environ["PTSS_SPHERE_ACCEL"]
+    off = frames(every_sphere_loop=True)
     assert np.array_equal(on[1], off[1]) and on[2] == off[2]
+    assert np.array_equal(on[0], off[0])
+
+
+def test_config5_shape_4k_12_bounces_chunked_equals_unchunked():
+    """The shape BASELINE.json configs[5] names — 3840x2160, 12 bounces, the 1,024-sphere scene — one pass of one sample
+    per pixel: 8.3 million rays through the chunk bounds (and the regrouped traversal) against the every-sphere loop."""
+    def frame(every_sphere_loop):
+        r = ptss.Renderer(ptss.Scene("stress"), 3840, 2160, max_iterations=12, sync_each_frame=False,
+                          every_sphere_loop=every_sphere_loop)
+        r.generate_frame()
+        out = (r.accumulator(), r.live_counts().copy(), r.total_ray_bounces())
+        r.close()
+        return out
+    on, off = frame(False), frame(True)
+    assert np.array_equal(on[1], off[1]) and on[2] == off[2]
+    assert on[1][0] == 3840 * 2160 and len(on[1]) == 12
     assert np.array_equal(on[0], off[0])
 
 

@@ -76,6 +76,7 @@ def test_no_display_buffer_and_external_buffers():
     acc = torch.zeros((w * h, 3), dtype=torch.int32, device="cuda")
     pix = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
     r.bind_accumulator(acc.data_ptr())        # torch owns totalPixelColors
+    torch.cuda.synchronize()                  # the zero-fills above ran on torch's default stream; `s` does not wait for it
     s = torch.cuda.Stream()
     r.set_stream(s.cuda_stream)
     for _ in range(3):

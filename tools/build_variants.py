@@ -10,6 +10,7 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 
 VARIANTS = {
+    "knobs": ["PTSS_TUNING_KNOBS=1"],   # reads PTSS_GRID_CAP / PTSS_SCENE_PATH from the environment (tools/sweep_env.sh)
     "w1": ["PTSS_MINWAVES=1"],
     "w4": ["PTSS_MINWAVES=4"],
     "w5": ["PTSS_MINWAVES=5"],
@@ -43,12 +44,25 @@ VARIANTS = {
     "a1": ["PTSS_ABLATE=1"],
     "a2": ["PTSS_ABLATE=2"],
     "a3": ["PTSS_ABLATE=3"],
+    "a4": ["PTSS_ABLATE=4"],   # no scatter
     "a7": ["PTSS_ABLATE=7"],
     "a8": ["PTSS_ABLATE=8"],   # no finishPath (tone map, accumulate, park RNG)
     "a64": ["PTSS_ABLATE=64"],    # finishPath without the accumulator atomics (S > 1)
     "a128": ["PTSS_ABLATE=128"],  # finishPath without parking the RNG state
     "a15": ["PTSS_ABLATE=15"],
-    "g2": ["PTSS_TRI_GUARD2=1"],  # triangle reciprocal with both range compares
+    "g2": ["PTSS_TRI_GUARD2=1"],
+    "r1": ["PTSS_SPHERE_UNROLL=0", "PTSS_TRI_STRAIGHT=0"],   # the round-1 loops
+    "ts2": ["PTSS_TRI_STRAIGHT=2"],                      # one exit kept, bare reciprocal, min3, selects
+    "nofs": ["PTSS_FRESNEL_SKIP=0"],
+    "ts2nofs": ["PTSS_TRI_STRAIGHT=2", "PTSS_FRESNEL_SKIP=0"],
+    "nots": ["PTSS_TRI_STRAIGHT=0"],                     # closest-hit triangle loop with wave-uniform exits
+    "row128": ["PTSS_ROW128=1"],                         # scene rows as 16-byte fetches (ds_read_b128)
+    "su25r": ["PTSS_SPHERE_UNROLL=25"],
+    "nosu": ["PTSS_SPHERE_UNROLL=0"],
+    "su1": ["PTSS_SPHERE_UNROLL=1"],    # closest hit: four spheres per trip
+    "su9": ["PTSS_SPHERE_UNROLL=9"],    # + dense shadow passes: two per trip
+    "su25": ["PTSS_SPHERE_UNROLL=25"],  # + lane-split shadow passes: two per trip
+    "su7": ["PTSS_SPHERE_UNROLL=7"],    # four per trip everywhere (spills)  # sphere candidate masks one sphere per trip (the round-1 loop)  # triangle reciprocal with both range compares
 }
 
 if __name__ == "__main__":

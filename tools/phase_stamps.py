@@ -10,8 +10,9 @@ import ptss  # noqa: E402
 
 names = ["ray load", "closest hit", "surfel + light sampling + enqueue", "dense shadow passes",
          "lambert + scatter + update", "finish (tonemap/accumulate/park)", "compaction", "-"]
-r = ptss.Renderer(ptss.Scene("mixed"), 1920, 1080, max_iterations=8, sync_each_frame=False)
-for _ in range(30):
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # sample lanes per pixel per pass
+r = ptss.Renderer(ptss.Scene("mixed"), 1920, 1080, max_iterations=8, sync_each_frame=False, samples_per_pass=S)
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()

@@ -10,7 +10,9 @@ import ptss  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-r = ptss.Renderer(ptss.Scene("stress"), 3840, 2160, max_iterations=12, sync_each_frame=False, samples_per_pass=S)
+chunked = (int(sys.argv[3]) != 0) if len(sys.argv) > 3 else True   # 0: cfg.everySphereLoop (the reference's loop)
+r = ptss.Renderer(ptss.Scene("stress"), 3840, 2160, max_iterations=12, sync_each_frame=False, samples_per_pass=S,
+                  every_sphere_loop=not chunked)
 r.generate_frame()
 r.synchronize()
 r0 = r.total_ray_bounces()

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/sweep
 for tag in "$@"; do
   lib=libptss_${tag}.so; [ "$tag" = base ] && lib=libptss.so
   if PTSS_LIBNAME=$lib python __graft_entry__.py smoke > gpurun_out/sweep/$tag.smoke 2>&1; then ok=parity-ok; else ok=PARITY-FAIL; fi
-  PTSS_LIBNAME=$lib python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline > gpurun_out/sweep/$tag.json 2> gpurun_out/sweep/$tag.err
+  PTSS_LIBNAME=$lib python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --no-s1-leg > gpurun_out/sweep/$tag.json 2> gpurun_out/sweep/$tag.err
   python - <<PY
 import json
 try:

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/sweep
 for tag in "$@"; do
   lib=libptss_${tag}.so; [ "$tag" = base ] && lib=libptss.so
-  PTSS_LIBNAME=$lib python bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline > gpurun_out/sweep/$tag.json 2> gpurun_out/sweep/$tag.err
+  PTSS_LIBNAME=$lib python bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-s1-leg > gpurun_out/sweep/$tag.json 2> gpurun_out/sweep/$tag.err
   python - <<PY
 import json
 try:
