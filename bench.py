@@ -27,7 +27,8 @@ ray-bounce: 76 B SoA state read + 76 B written) / HIP-event tim
 `valu.issue_frac` = wave-level VALU instructions per launch (SQ_INSTS_VALU, from the committed PMC summary
 profiles/pmc_counters.json, taken with this configuration) / (1,024 SIMDs x 2.4 GHz / 2 cycles x the launch time
 measured in THIS run). `cpu_baseline` times oracle/ (the CPU restatement, OpenMP) on a bounded slice of the same
-workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode.
+workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode (one context);
+`s1_two_shards_two_streams_mrays_per_s` the same frame as two pixel-band shards on two streams of this one GPU.
 """
 import argparse
 import json
@@ -97,23 +98,37 @@ def pmc_counters(config, samples):
     return None, None
 
 
-def s1_leg(ptss, torch, scene, cfg, stream, passes=200, warmup=20):
-    """The reference's own mode on the same frame: one sample per pixel per generateFrame call (CudaTracer.cu:587-647)."""
-    r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
-                      sync_each_frame=False, samples_per_pass=1)
-    r.set_stream(stream.cuda_stream)
-    pix = torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda")
-    for _ in range(warmup):
-        r.generate_frame(pix.data_ptr())
+def s1_leg(ptss, torch, scene, cfg, shards=1, passes=200, warmup=20):
+    """The reference's own mode on the same frame: one sample per pixel per generateFrame call (CudaTracer.cu:587-647).
+    shards = 1: one context, the reference's semantics to the letter. shards = K > 1: the same frame as K interleaved
+    pixel-band shards (cfg.tileWorld = K, the multi-GPU sharding) in THIS process on this one GPU, each on its own stream,
+    so that the tail of one shard's small launches overlaps the other shards' kernels; same image whenever more than 128
+    rays stay alive frame-wide (the sharding caveat)."""
+    rs, pix = [], []
+    for k in range(shards):
+        r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
+                          tile_rank=k, tile_world=shards, band_rows=BAND_ROWS, sync_each_frame=False, samples_per_pass=1)
+        r.set_stream(torch.cuda.Stream().cuda_stream if shards > 1 else torch.cuda.current_stream().cuda_stream)
+        rs.append(r)
+        pix.append(torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda"))
     torch.cuda.synchronize()
-    r0 = r.total_ray_bounces()
+
+    def frame():
+        for r, p in zip(rs, pix):
+            r.generate_frame(p.data_ptr())
+
+    for _ in range(warmup):
+        frame()
+    torch.cuda.synchronize()
+    r0 = sum(r.total_ray_bounces() for r in rs)
     t0 = time.perf_counter()
     for _ in range(passes):
-        r.generate_frame(pix.data_ptr())
+        frame()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rays = r.total_ray_bounces() - r0
-    r.close()
+    rays = sum(r.total_ray_bounces() for r in rs) - r0
+    for r in rs:
+        r.close()
     return round(rays / dt / 1e6, 2), round(dt / passes * 1e3, 4)
 
 
@@ -291,9 +306,12 @@ def main():
                             "the HBM and VALU-issue fractions")
             out["roofline"] = roof
         if world == 1 and not args.no_s1_leg:
-            v, ms = s1_leg(ptss, torch, scene, cfg, stream)
+            v, ms = s1_leg(ptss, torch, scene, cfg)
             out["s1_mrays_per_s"] = v
             out["s1_ms_per_pass"] = ms
+            v2, ms2 = s1_leg(ptss, torch, scene, cfg, shards=2)
+            out["s1_two_shards_two_streams_mrays_per_s"] = v2
+            out["s1_two_shards_two_streams_ms_per_pass"] = ms2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -104,7 +104,7 @@ namespace {
 
 // ---- sphere acceleration (scenes with many spheres) ------------------------------------------------------------------
 // The kernel may skip a sphere only if the discriminant the reference computes for it (Primitives.h:107-118, float32)
-// is certainly negative. Spheres are sorted along a Morton curve and cut into chunks of kChunkSpheres; each chunk gets
+// is certainly negative. Spheres are sorted spatially (spatialOrder) and cut into chunks of kChunkSpheres; each chunk gets
 // a bounding sphere (C, R) with |c_i - C| + r_i <= R for its members. For a ray (o, d) with | |d|^2 - 1 | <= eps = 1e-5
 // let vC = o - C, vv = vC.vC, dv = d.vC. The kernel culls the chunk iff
 //       vv (1 - mu) - (1 + 2 eps) dv^2  >  R^2 (1 + m)^3        with m = 5e-3, mu = m + m^2.
@@ -141,39 +141,40 @@ bool accelEligible(const ptss_scene_desc& s) {
     return true;
 }
 
-// sorted position -> original index, along a 30-bit Morton curve over the box of the centres (ties by original index)
-std::vector<int> mortonOrder(const ptss_scene_desc& s) {
-    const int n = (int)s.numSpheres;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int i = 0; i < n; ++i) {
-        const double c[3] = {s.spheres[i].position.x, s.spheres[i].position.y, s.spheres[i].position.z};
+// sorted position -> original index. The spheres are split recursively at the median of their centres along the axis of
+// largest extent (a kd-tree built by std::nth_element; ties by original index, so the order is deterministic), the cut
+// placed at a multiple of 64 spheres while a part holds more than 64 and at a multiple of kChunkSpheres below that: every
+// chunk of kChunkSpheres consecutive positions is a leaf and every 64 consecutive positions a subtree. Against round 1's
+// Morton curve (whose jumps put far-apart spheres into one chunk) a ray of the configs[5] scene meets about half as many
+// chunk bounds. Any permutation is legal here: the traversal decides ties by ORIGINAL index (offSphereOrig).
+void kdSplit(const ptss_scene_desc& s, std::vector<int>& idx, int lo, int hi) {
+    const int n = hi - lo;
+    if (n <= ptss::kChunkSpheres) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lo; i < hi; ++i) {
+        const float c[3] = {s.spheres[idx[i]].position.x, s.spheres[idx[i]].position.y, s.spheres[idx[i]].position.z};
         for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], c[a]);
-            hi[a] = std::max(hi[a], c[a]);
+            mn[a] = std::min(mn[a], c[a]);
+            mx[a] = std::max(mx[a], c[a]);
         }
     }
-    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
-        v &= 0x3ffu;
-        v = (v | (v << 16)) & 0x030000ffu;
-        v = (v | (v << 8)) & 0x0300f00fu;
-        v = (v | (v << 4)) & 0x030c30c3u;
-        v = (v | (v << 2)) & 0x09249249u;
-        return v;
-    };
-    std::vector<std::pair<uint32_t, int>> keyed(n);
-    for (int i = 0; i < n; ++i) {
-        const double c[3] = {s.spheres[i].position.x, s.spheres[i].position.y, s.spheres[i].position.z};
-        uint32_t code = 0;
-        for (int a = 0; a < 3; ++a) {
-            const double ext = hi[a] - lo[a];
-            const double f = ext > 0 ? (c[a] - lo[a]) / ext : 0.0;
-            code |= spread((uint32_t)std::min(1023.0, std::max(0.0, f * 1024.0))) << a;
-        }
-        keyed[i] = {code, i};
-    }
-    std::sort(keyed.begin(), keyed.end());
-    std::vector<int> order(n);
-    for (int i = 0; i < n; ++i) order[i] = keyed[i].second;
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    const int unit = n > 64 ? 64 : ptss::kChunkSpheres;
+    int left = ((n / 2 + unit - 1) / unit) * unit;  // spheres in the lower part: about half, a whole number of units
+    if (left >= n) left -= unit;
+    if (left <= 0) return;
+    auto key = [&](int i) { return axis == 0 ? s.spheres[i].position.x : (axis == 1 ? s.spheres[i].position.y : s.spheres[i].position.z); };
+    std::nth_element(idx.begin() + lo, idx.begin() + lo + left, idx.begin() + hi,
+                     [&](int a, int b) { return key(a) < key(b) || (key(a) == key(b) && a < b); });
+    kdSplit(s, idx, lo, lo + left);
+    kdSplit(s, idx, lo + left, hi);
+}
+std::vector<int> spatialOrder(const ptss_scene_desc& s) {
+    std::vector<int> order((size_t)s.numSpheres);
+    for (size_t i = 0; i < s.numSpheres; ++i) order[i] = (int)i;
+    kdSplit(s, order, 0, (int)s.numSpheres);
     return order;
 }
 
@@ -232,7 +233,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));
     std::vector<int> order;
     if (accel) {
-        order = mortonOrder(s);
+        order = spatialOrder(s);
         while ((int)order.size() < sphereRows) order.push_back(order.back());  // pad the last chunk with copies
     } else {
         order.resize(s.numSpheres);

@@ -97,10 +97,12 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #endif
 constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workgroup
 #ifndef PTSS_CHUNK
-#define PTSS_CHUNK 8
+#define PTSS_CHUNK 16   // with the kd-split order (ptss_api.hip spatialOrder), configs[5] scene at S = 4, same box:
+                        // 4: 2,224, 8: 3,762, 16: 4,158-4,167, 32: 3,476 Mrays/s — every lane tests every chunk bound, so
+                        // halving their number is worth more than the tighter fit of smaller chunks
 #endif
 constexpr int kChunkSpheres = PTSS_CHUNK;
-static_assert((kChunkSpheres & (kChunkSpheres - 1)) == 0, "chunk size must be a power of two");   // spheres per chunk of the many-sphere traversal (4 / 8 / 16 measured)
+static_assert((kChunkSpheres & (kChunkSpheres - 1)) == 0, "chunk size must be a power of two");   // spheres per chunk of the many-sphere traversal
 constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
 constexpr int kCountStride = 32;            // one counter per 128-B line
 constexpr int kCountWords = (kMaxBounces + 1) * kShards * kCountStride;

@@ -471,6 +471,18 @@ __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec
     return unitDir ? mask : ((cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u));
 }
 
+// Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
+// from position (chunk mod kChunkSpheres) on, wrapping, so that the 16-byte gathers of a wave spread over the LDS banks;
+// verdicts enter through the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
+// of that mask back into the sphere's slot inside the chunk. The traversal is order-free (ties go by original index).
+__device__ __forceinline__ uint32_t chunkCandidates(const float4* spheres /* sc + L.offSphere */, int base, int chunk, vec3 o, vec3 d) {
+    uint32_t rev = 0;
+#pragma unroll 4
+    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
+    return rev;
+}
+__device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSpheres - 1 - bit) + chunk) & (kChunkSpheres - 1); }
+
 // The chunk bits of up to 128 chunks (4 words) are gathered first and walked in ONE per-lane loop: the wave then runs as
 // long as its busiest lane's TOTAL, not the sum over 32-chunk groups of each group's busiest lane.
 struct ChunkBits {
@@ -509,16 +521,9 @@ __device__ __forceinline__ void closestSpheresChunked(const float4* sc, const fl
         while (anyChunk(chunks)) {
             const int chunk = g0 + popChunk(chunks);
             const int base = chunk * kChunkSpheres;
-            uint32_t mask = 0;
-            // Lanes sit in different chunks, and a chunk is kChunkSpheres x 16 B = a whole number of sweeps over the 32 LDS
-            // banks: each lane starts at sphere (chunk mod kChunkSpheres) of its chunk so that the gathers of a wave
-            // spread over the banks (measured: conflicts are 3 % of cycles).
-            for (int i = 0; i < kChunkSpheres; ++i) {
-                const int j = (i + chunk) & (kChunkSpheres - 1);
-                if (sphereMayHit(sc[L.offSphere + base + j], o, d)) mask |= 1u << j;
-            }
+            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, o, d);
             while (mask != 0) {
-                const int j = __builtin_ctz(mask);
+                const int j = chunkSlot(__builtin_ctz(mask), chunk);
                 mask &= mask - 1;
                 float t;
                 if (sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t)) {  // t <= h.distance
@@ -543,13 +548,9 @@ __device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLa
         while (anyChunk(chunks)) {
             const int chunk = g0 + popChunk(chunks);
             const int base = chunk * kChunkSpheres;
-            uint32_t mask = 0;
-            for (int i = 0; i < kChunkSpheres; ++i) {  // rotated start: see closestSpheresChunked
-                const int j = (i + chunk) & (kChunkSpheres - 1);
-                if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
-            }
+            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, lo, w_i);
             while (mask != 0) {
-                const int j = __builtin_ctz(mask);
+                const int j = chunkSlot(__builtin_ctz(mask), chunk);
                 mask &= mask - 1;
                 float t;
                 if (sphereTest(sc[L.offSphere + base + j], lo, w_i, distance, t)) {
@@ -653,15 +654,11 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
             const int base = (work ? chunk : 0) * kChunkSpheres;
             const vec3 ro = v3(rayTab[0 * 64 + owner], rayTab[1 * 64 + owner], rayTab[2 * 64 + owner]);
             const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
-            uint32_t mask = 0;
-            for (int i = 0; i < kChunkSpheres; ++i) {
-                const int j = (i + chunk) & (kChunkSpheres - 1);
-                if (sphereMayHit(sc[L.offSphere + base + j], ro, rd)) mask |= 1u << j;
-            }
+            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, ro, rd);
             if (!work) mask = 0;
             unsigned long long key = ~0ull;
             while (mask != 0) {
-                const int j = __builtin_ctz(mask);
+                const int j = chunkSlot(__builtin_ctz(mask), chunk);
                 mask &= mask - 1;
                 float t;
                 if (sphereTest(sc[L.offSphere + base + j], ro, rd, ptm::inf(), t)) {
@@ -717,13 +714,9 @@ __device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLa
             if (anyChunk(mine)) {
                 const int chunk = g0 + popChunk(mine);
                 const int base = chunk * kChunkSpheres;
-                uint32_t mask = 0;
-                for (int i = 0; i < kChunkSpheres; ++i) {
-                    const int j = (i + chunk) & (kChunkSpheres - 1);
-                    if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
-                }
+                uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, lo, w_i);
                 while (mask != 0) {
-                    const int j = __builtin_ctz(mask);
+                    const int j = chunkSlot(__builtin_ctz(mask), chunk);
                     mask &= mask - 1;
                     float t;
                     if (sphereTest(sc[L.offSphere + base + j], lo, w_i, distance, t)) {
@@ -783,14 +776,10 @@ __device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLa
             const vec3 so = v3(seg[0 * kQueueCapConst + owner], seg[1 * kQueueCapConst + owner], seg[2 * kQueueCapConst + owner]);
             const vec3 sd = v3(seg[3 * kQueueCapConst + owner], seg[4 * kQueueCapConst + owner], seg[5 * kQueueCapConst + owner]);
             const float reach = seg[6 * kQueueCapConst + owner];
-            uint32_t mask = 0;
-            for (int i = 0; i < kChunkSpheres; ++i) {
-                const int j = (i + chunk) & (kChunkSpheres - 1);
-                if (sphereMayHit(sc[L.offSphere + base + j], so, sd)) mask |= 1u << j;
-            }
+            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, so, sd);
             if (!work) mask = 0;
             while (mask != 0) {
-                const int j = __builtin_ctz(mask);
+                const int j = chunkSlot(__builtin_ctz(mask), chunk);
                 mask &= mask - 1;
                 float t;
                 if (sphereTest(sc[L.offSphere + base + j], so, sd, reach, t)) {

@@ -31,7 +31,8 @@ VARIANTS = {
     "warm16": ["PTSS_WARM=16"],
     "norg": ["PTSS_REGROUP=0"],  # many-sphere scenes: every lane walks its own chunks in the closest hit too
     "ck4": ["PTSS_CHUNK=4"],
-    "ck16": ["PTSS_CHUNK=16"],
+    "ck8": ["PTSS_CHUNK=8"],
+    "ck32": ["PTSS_CHUNK=32"],
     "chist": ["PTSS_CHIST=1"],
     "nosplit": ["PTSS_SPLIT_SPARSE=0"],
     "powq": ["PTSS_QUANT_TABLE=0"],  # literal clamp/pow/scale tone map
