@@ -146,6 +146,7 @@ def main():
     # (collectives staged through host memory) in place of RCCL.
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dump-frame", default=None, help="tests: rank 0 saves the whole-frame integer accumulator (.npy)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else cfg["steps"]
@@ -225,10 +226,12 @@ def main():
         sizes = [len(ptss.tile_rows(H, BAND_ROWS, k, world)) * W for k in range(world)]
         frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], W, H, BAND_ROWS)
         assert frame.shape == (W * H, 3) and int(frame.max()) <= 255 * (steps + args.warmup) * samples
-        dump = os.environ.get("PTSS_BENCH_DUMP_FRAME")   # tests only: the gathered accumulator, for comparison with one context
-        if dump:
+        if args.dump_frame:
             import numpy as np
-            np.save(dump, frame)
+            np.save(args.dump_frame, frame)
+    if rank == 0 and dist is None and args.dump_frame:
+        import numpy as np
+        np.save(args.dump_frame, acc.cpu().numpy())
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
     stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device=coll_dev)

@@ -1744,11 +1744,15 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
             }
     } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
         for (int s = 0; s < kShards; ++s) {
-            const uint32_t n = fb.counts[countIndex(stop, s)];
+            // n <= 128 = blockDim.x here by the guard that stopped the loop; clamped all the same, and a slot whose pixel
+            // or sample lane is out of range is skipped rather than written through: a stale slot must never be able to
+            // fault the device (a GPU memory fault aborts the calling process — DESIGN.md §4c, the round-1 abort)
+            uint32_t n = fb.counts[countIndex(stop, s)];
+            n = n < blockDim.x ? n : blockDim.x;
             if (i < n) {
                 RayRegs ray;
                 loadRay(tileBlock(fb.pool[stop & 1] + (size_t)s * fb.regionCap * kRayPlanes, (i / kBlock) * kBlock), i % kBlock, ray);
-                finishPath(fb, ray, fb.quantTable);
+                if (pixOf(ray.pix) < fb.numPixels && laneOf(ray.pix) < fb.samples) finishPath(fb, ray, fb.quantTable);
             }
         }
     }

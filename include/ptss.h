@@ -34,7 +34,12 @@ typedef struct ptss_render_config {
     int device;                  /* HIP device ordinal (reference: cudaChooseDevice, CudaUtils.h:49-57) */
     /* Pixel-tile shard (north_star): this context owns the rows y with
      * (y / bandRows) % tileWorld == tileRank. tileWorld = 1 renders the whole frame. The RNG
-     * subsequence is the GLOBAL pixel index, so the image does not depend on the sharding. */
+     * subsequence is the GLOBAL pixel index, so the image does not depend on the sharding — with ONE exception:
+     * the reference stops bouncing once <= 128 rays are alive in the WHOLE frame (CudaTracer.cu:622); a shard cannot
+     * know that count without a collective per bounce, so a context with tileWorld > 1 never stops early (and
+     * ptss_live_counts reports its own rays down to 0). Sharded and unsharded images are identical whenever more than
+     * 128 rays stay alive frame-wide at every bounce that runs (always, at the benchmark sizes); they differ in tiny
+     * frames and in frames whose last few rays outlive the guard (tests/test_gpu_tiles.py pins both behaviours). */
     int tileRank, tileWorld, bandRows;
     int syncEachFrame;     /* 1: block on the stop event and record ms each frame, as CudaTracer.cu:639-642 */
     int floatAccumulator;  /* 1: also keep a linear float32 sum of radiance0 per pixel */

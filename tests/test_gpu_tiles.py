@@ -64,3 +64,28 @@ def test_full_size_properties_1080p():
     assert np.array_equal(px[:, :3], ((acc * np.float32(1.0 / spp)) + np.float32(0.5)).astype(np.uint8))
     for r in [a, b] + parts:
         r.close()
+
+
+def test_loop_guard_is_a_whole_frame_quantity_only_unsharded():
+    """The one documented difference (include/ptss.h): the reference's `numRays > 128` guard
+    (CudaTracer.cu:622) is evaluated on the frame's live count; a shard cannot know it and never stops early.
+    16x8 = 128 pixels: unsharded, not even bounce 0 runs (the oracle agrees: every sample is radiance 0); two shards of 64
+    pixels each trace their rays to the end."""
+    w, h, bounces = 16, 8, 4
+    scene = ptss.Scene("cornell")
+    whole = ptss.Renderer(scene, w, h, max_iterations=bounces)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces)
+    parts = [ptss.Renderer(scene, w, h, max_iterations=bounces, tile_rank=k, tile_world=2, band_rows=4) for k in range(2)]
+    for _ in range(2):
+        whole.generate_frame()
+        o.generate_frame()
+        for p in parts:
+            p.generate_frame()
+    assert np.array_equal(whole.accumulator(), o.accumulator()) and whole.accumulator().max() == 0
+    assert whole.live_counts().sum() == 0 and whole.total_ray_bounces() == 0
+    for p in parts:
+        assert p.live_counts()[0] == 64                     # its own rays, although 64 <= 128
+    sharded = tiles.untile([p.accumulator() for p in parts], w, h, 4)
+    assert sharded.max() > 0 and sum(p.total_ray_bounces() for p in parts) > 128
+    for r in [whole] + parts:
+        r.close()
