@@ -40,6 +40,11 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
                           // PTSS_DEFER_LOADS the only scratch left is in a cold IEEE-division escape block. Measured, same box:
                           // 5 waves (96 VGPRs) 13.3, 6 (80) 14.2, 7 (72) 14.5, 8 (64, spills) 11.4 Grays/s
 #endif
+#ifndef PTSS_MINWAVES_FIRST
+#define PTSS_MINWAVES_FIRST 6   // bounce 0's instantiation (eye rays fused in, camera-origin tests) has its own register budget:
+                                // at 7 waves it spills 32 B (18 scratch accesses per tile), at 6 (80 VGPRs) none —
+                                // same-box A/B: that kernel 3,035 -> 2,826 us per launch, the pass +0.9 %
+#endif
 #ifndef PTSS_ABLATE
 #define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
 #endif
@@ -91,6 +96,10 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 // 1: scatter evaluates the Snell / Fresnel terms only for lanes whose material reads them
 #ifndef PTSS_FRESNEL_SKIP
 #define PTSS_FRESNEL_SKIP 1
+#endif
+// experiment, off: survivors leave a wave ordered by class (1: material class of the surface just left, 2: direction octant)
+#ifndef PTSS_CLASS_RANK
+#define PTSS_CLASS_RANK 0
 #endif
 #ifndef PTSS_SHARDS
 #define PTSS_SHARDS 16

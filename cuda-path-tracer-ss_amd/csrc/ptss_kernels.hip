@@ -86,26 +86,38 @@ __device__ __forceinline__ uint32_t slotWord(uint32_t slot) {  // word offset of
     return (slot / kBlock) * (uint32_t)(kRayPlanes * kBlock) + (slot % kBlock);
 }
 
+// One word of a block: scalar base + (32-bit lane byte offset, zero-extended) + compile-time plane offset — the form
+// global_load/store take as `saddr + voffset + imm` (no 64-bit vector address pair per group of planes).
+__device__ __forceinline__ float ldPlane(const float* __restrict__ block, uint32_t laneBytes, int plane) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(block) + (size_t)laneBytes + (size_t)plane * (kBlock * sizeof(float)));
+}
+__device__ __forceinline__ void stPlane(float* __restrict__ region, uint32_t wordBytes, int plane, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(region) + (size_t)wordBytes + (size_t)plane * (kBlock * sizeof(float))) = v;
+}
+
 // PTSS_DEFER_LOADS fetches a ray's planes in the order the tile needs them, so that no plane occupies registers before
 // its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
 // throughput / pixel for the update at the end. `block` = the tile's block (wave-uniform), w = the ray's lane in it.
 __device__ __forceinline__ void loadRayGeometry(const float* __restrict__ block, uint32_t w, RayRegs& r) {
-    r.o = vec3{block[kOx * kBlock + w], block[kOy * kBlock + w], block[kOz * kBlock + w]};
-    r.d = vec3{block[kDx * kBlock + w], block[kDy * kBlock + w], block[kDz * kBlock + w]};
+    const uint32_t b = w * 4u;
+    r.o = vec3{ldPlane(block, b, kOx), ldPlane(block, b, kOy), ldPlane(block, b, kOz)};
+    r.d = vec3{ldPlane(block, b, kDx), ldPlane(block, b, kDy), ldPlane(block, b, kDz)};
     r.active = true;
 }
 __device__ __forceinline__ void loadRayRng(const float* __restrict__ block, uint32_t w, RayRegs& r) {
-    r.rng.v[0] = asU(block[kR0 * kBlock + w]);
-    r.rng.v[1] = asU(block[kR1 * kBlock + w]);
-    r.rng.v[2] = asU(block[kR2 * kBlock + w]);
-    r.rng.v[3] = asU(block[kR3 * kBlock + w]);
-    r.rng.v[4] = asU(block[kR4 * kBlock + w]);
-    r.rng.d = asU(block[kRd * kBlock + w]);
+    const uint32_t b = w * 4u;
+    r.rng.v[0] = asU(ldPlane(block, b, kR0));
+    r.rng.v[1] = asU(ldPlane(block, b, kR1));
+    r.rng.v[2] = asU(ldPlane(block, b, kR2));
+    r.rng.v[3] = asU(ldPlane(block, b, kR3));
+    r.rng.v[4] = asU(ldPlane(block, b, kR4));
+    r.rng.d = asU(ldPlane(block, b, kRd));
 }
 __device__ __forceinline__ void loadRayRadiance(const float* __restrict__ block, uint32_t w, RayRegs& r) {
-    r.L0 = vec3{block[kL0x * kBlock + w], block[kL0y * kBlock + w], block[kL0z * kBlock + w]};
-    r.T = vec3{block[kTx * kBlock + w], block[kTy * kBlock + w], block[kTz * kBlock + w]};
-    r.pix = asU(block[kPix * kBlock + w]);
+    const uint32_t b = w * 4u;
+    r.L0 = vec3{ldPlane(block, b, kL0x), ldPlane(block, b, kL0y), ldPlane(block, b, kL0z)};
+    r.T = vec3{ldPlane(block, b, kTx), ldPlane(block, b, kTy), ldPlane(block, b, kTz)};
+    r.pix = asU(ldPlane(block, b, kPix));
 }
 __device__ __forceinline__ void loadRay(const float* __restrict__ block, uint32_t w, RayRegs& r) {
     loadRayGeometry(block, w, r);
@@ -113,19 +125,20 @@ __device__ __forceinline__ void loadRay(const float* __restrict__ block, uint32_
     loadRayRadiance(block, w, r);
 }
 
-// `at` = region + slotWord(slot): the ray's word in plane 0 of its block
-__device__ __forceinline__ void storeRay(float* __restrict__ at, const RayRegs& r) {
-    at[kOx * kBlock] = r.o.x;  at[kOy * kBlock] = r.o.y;  at[kOz * kBlock] = r.o.z;
-    at[kDx * kBlock] = r.d.x;  at[kDy * kBlock] = r.d.y;  at[kDz * kBlock] = r.d.z;
-    at[kL0x * kBlock] = r.L0.x; at[kL0y * kBlock] = r.L0.y; at[kL0z * kBlock] = r.L0.z;
-    at[kTx * kBlock] = r.T.x;  at[kTy * kBlock] = r.T.y;  at[kTz * kBlock] = r.T.z;
-    at[kPix * kBlock] = asF(r.pix);
-    at[kR0 * kBlock] = asF(r.rng.v[0]);
-    at[kR1 * kBlock] = asF(r.rng.v[1]);
-    at[kR2 * kBlock] = asF(r.rng.v[2]);
-    at[kR3 * kBlock] = asF(r.rng.v[3]);
-    at[kR4 * kBlock] = asF(r.rng.v[4]);
-    at[kRd * kBlock] = asF(r.rng.d);
+// the ray goes to region slot `slot` (its word in plane 0 of its block: slotWord)
+__device__ __forceinline__ void storeRay(float* __restrict__ region, uint32_t slot, const RayRegs& r) {
+    const uint32_t b = slotWord(slot) * 4u;   // < 2^32: ptss_create bounds a region's bytes
+    stPlane(region, b, kOx, r.o.x);   stPlane(region, b, kOy, r.o.y);   stPlane(region, b, kOz, r.o.z);
+    stPlane(region, b, kDx, r.d.x);   stPlane(region, b, kDy, r.d.y);   stPlane(region, b, kDz, r.d.z);
+    stPlane(region, b, kL0x, r.L0.x); stPlane(region, b, kL0y, r.L0.y); stPlane(region, b, kL0z, r.L0.z);
+    stPlane(region, b, kTx, r.T.x);   stPlane(region, b, kTy, r.T.y);   stPlane(region, b, kTz, r.T.z);
+    stPlane(region, b, kPix, asF(r.pix));
+    stPlane(region, b, kR0, asF(r.rng.v[0]));
+    stPlane(region, b, kR1, asF(r.rng.v[1]));
+    stPlane(region, b, kR2, asF(r.rng.v[2]));
+    stPlane(region, b, kR3, asF(r.rng.v[3]));
+    stPlane(region, b, kR4, asF(r.rng.v[4]));
+    stPlane(region, b, kRd, asF(r.rng.d));
 }
 
 // ---- Sphere::intersectRay, Primitives.h:107-175. sp = {centre, radius^2}. ---------------------
@@ -1382,7 +1395,7 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
 // that scenes without it run exactly the code they ran before.
 template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
-__global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
+__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : PTSS_MINWAVES)) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
    FrameBuffers fb, const float4* __restrict__ sceneBlob,
                                                                       SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
     extern __shared__ float4 lds[];
@@ -1628,6 +1641,13 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
 
         // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
         bool alive = false;
+        [[maybe_unused]] uint32_t classOfScatter = 3;   // PTSS_CLASS_RANK = 1: 0 diffuse material, 1 mirror-like, 2 refractive, 3 other
+#if PTSS_CLASS_RANK == 1
+        if (hit) {
+            const float4 m0 = mat[0], m1 = mat[1];
+            classOfScatter = (mat[2].w > 0.0f) ? 2u : ((m1.w > 0.0f) ? 1u : ((m0.w > 0.0f) ? 0u : 3u));
+        }
+#endif
 #if PTSS_DEFER_LOADS
         if constexpr (!kFirst) {
             if (valid) loadRayRadiance(tileBlock(in, base), threadIdx.x, ray);
@@ -1673,8 +1693,32 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
                     base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], (uint32_t)__popcll(live));
                 slot = base0;  // consumed after the finish work below
                 if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
+#if PTSS_CLASS_RANK   // experiment ("material-class ray sorting"): survivors leave the wave ordered by class
+                // first, lane second — class = the lobe the ray just left through (PTSS_CLASS_RANK = 1: diffuse / mirror-like /
+                // refracted / other, from the throughput factor's origin) or the octant of its new direction (= 2). Legal:
+                // the random stream travels with the ray, so the image does not depend on slot order (parity tests unchanged).
+                {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+#if PTSS_CLASS_RANK == 2
+                    const uint32_t cls = (ray.d.x < 0 ? 1u : 0u) | (ray.d.y < 0 ? 2u : 0u) | (ray.d.z < 0 ? 4u : 0u);
+                    constexpr uint32_t kClasses = 8;
+#else
+                    const uint32_t cls = classOfScatter;
+                    constexpr uint32_t kClasses = 4;
+#endif
+                    uint32_t rank = 0, before = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < kClasses; ++c) {
+                        const unsigned long long m = __ballot(alive && cls == c);
+                        rank = (cls == c) ? before + (uint32_t)__popcll(m & below) : rank;
+                        before += (uint32_t)__popcll(m);
+                    }
+                    slot = __shfl(slot, leader) + rank;
+                }
+#else
                 slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
-                if (alive) storeRay(out + slotWord(slot), ray);
+#endif
+                if (alive) storeRay(out, slot, ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
                 finishPath(fb, ray, quantT);
             }
@@ -1698,7 +1742,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : PTSS_MINWAVES) void bounceKern
             __syncthreads();
             uint32_t slot = scratch[8] + rank;
             for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
-            if (alive) storeRay(out + slotWord(slot), ray);
+            if (alive) storeRay(out, slot, ray);
             __syncthreads();  // scratch is rewritten by the next tile
         }
 #endif

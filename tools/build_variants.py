@@ -11,6 +11,10 @@ spec.loader.exec_module(b)
 
 VARIANTS = {
     "knobs": ["PTSS_TUNING_KNOBS=1"],   # reads PTSS_GRID_CAP / PTSS_SCENE_PATH from the environment (tools/sweep_env.sh)
+    "cr1": ["PTSS_CLASS_RANK=1"],   # survivors ranked by material class inside the wave
+    "cr2": ["PTSS_CLASS_RANK=2"],   # ... by direction octant
+    "f7": ["PTSS_MINWAVES_FIRST=7"],   # bounce 0 at 6 waves per SIMD (80 VGPRs)
+    "f5": ["PTSS_MINWAVES_FIRST=5"],
     "w1": ["PTSS_MINWAVES=1"],
     "w4": ["PTSS_MINWAVES=4"],
     "w5": ["PTSS_MINWAVES=5"],

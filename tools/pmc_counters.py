@@ -48,7 +48,12 @@ if insts:
     entry["valu_insts_per_launch"] = round(mean(insts))
     entry["valu_lanes_active"] = round(sum(thr.values()) / (64.0 * sum(insts.values())), 4)
     # mid-bounce instantiation: <kLast = false, ..., kFirst = false, ...>
-    mid = {k: v for k, v in insts.items() if "bounceKernel<false, " in names[k] and ", false, " in names[k].split("bounceKernel<false, ")[1][5:]}
+    import re
+
+    def targs(n):  # <kLast, kSceneInLds, kFirst, kAccel>
+        m = re.search(r"bounceKernel<(\w+), (\w+), (\w+), (\w+)>", n)
+        return m.groups() if m else None
+    mid = {k: v for k, v in insts.items() if targs(names[k]) and targs(names[k])[0] == "false" and targs(names[k])[2] == "false"}
     try:
         b = json.load(open(os.path.join(src, "bench.json")))
         live = b["live_counts"]
