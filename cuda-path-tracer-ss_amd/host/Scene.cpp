@@ -42,6 +42,14 @@ Material cookTorrance(vec3 diffuse, vec3 specular, float roughness) {
 Scene::Scene() {}
 Scene::~Scene() {}
 
+// rand() of the reference is MSVC v120's, unseeded (Scene.cpp:3, CudaTracer.vcxproj): the LCG below with RAND_MAX =
+// 32767 [unverifiable offline]. UNPINNED ASSUMPTION beside it: the reference draws a sphere's coordinates as constructor
+// ARGUMENTS — vec3(rnd(5.0f) - 2.5f, rnd(5.0f) - 2.5f, rnd(7.0f) - 9.0f) (Scene.cpp:161, 219) — and C++ leaves the
+// evaluation order of function arguments unspecified (MSVC commonly evaluates them right to left). The generators here
+// draw x, then y, then z (left to right), so the "same spheres every time" layout of the default / mixed / lambert
+// presets is self-consistent but may be the reference's with x and z draws swapped; nothing the reference holds can
+// decide it (its image.tga shows the defined spheres of the Cornell preset, which draw nothing). Statistically the two
+// layouts are the same scene: 20 spheres of the same size distribution in the same box.
 int Scene::nextRand() {
     randState = randState * 214013u + 2531011u;
     return (int)((randState >> 16) & 0x7fffu);

@@ -70,6 +70,6 @@ try:
 except (OSError, ValueError):
     allc = {}
 allc[f"{config}_s{S}"] = entry
-allc["source"] = "profiles/%s/ (tools/profile_round.sh, separate rocprofv3 --pmc passes)" % os.path.basename(src.rstrip("/"))
+allc["source"] = "profiles/%s/<config>/ (tools/profile_round.sh, separate rocprofv3 --pmc passes)" % os.path.basename(os.path.dirname(src.rstrip("/")))
 json.dump(allc, open(path, "w"), indent=1)
 print(json.dumps({f"{config}_s{S}": entry}, indent=1))
