@@ -194,7 +194,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     const int sphereAlloc = accel ? sphereRows : (sphereRows + 3) / 4 * 4;
     L.offSphere = off;      off += sphereAlloc;
     if (!accel) { L.offSphereMat = off; off += (sphereRows + 3) / 4; }
-    L.offChunk = off;       off += L.numChunks;
+    L.offChunk = off;       off += (L.numChunks + 3) / 4 * 4;   // bound rows padded to a multiple of four (zero rows: chunkMask drops their bits)
     L.offTri = off;         off += 3 * L.numTriangles;
     L.offTriNormal = off;   off += 3 * L.numTriangles;
     L.offTriVert = off;     off += 2 * L.numTriangles;

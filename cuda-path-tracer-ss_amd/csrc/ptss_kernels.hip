@@ -469,19 +469,33 @@ constexpr float kAccelMu = 5e-3f + 5e-3f * 5e-3f;   // m + m^2
 constexpr float kAccelDirEps = 1e-5f;               // | |d|^2 - 1 | up to which a direction counts as unit
 constexpr float kAccelDvScale = 1.0f + 2e-5f;       // 1 / (1 - eps) rounded up
 
+// One chunk bound's verdict ("this lane's ray may touch the chunk") shifted into `rev` through the carry, as shiftInSphere does
+// for spheres. The verdict is assembled from three direct compares as wave masks (scalar and / or / not) and handed to
+// v_addc as its carry-in SGPR pair: no v_cndmask, no v_or, no v_mov for the bit.
+__device__ __forceinline__ void shiftInChunk(uint32_t& rev, float4 b, vec3 o, vec3 d) {
+    const vec3 v = o - xyz(b);
+    const float dv = dot(d, v);
+    const float vv = dot(v, v);
+    const float dv2 = dv * dv;
+    const unsigned long long lineClear = maskOf((vv * (1.0f - kAccelMu) - kAccelDvScale * dv2) > b.w);   // the LINE misses the chunk
+    const unsigned long long behind = maskOf(dv > 0.0f) & maskOf(dv2 * (1.0f - 2e-5f) > b.w + kAccelMu * vv);  // it lies behind the origin
+    const unsigned long long may = ~(lineClear | behind);  // not provably out of reach (a NaN lands here too)
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(rev) : "s"(may) : "vcc");
+}
+// four bounds per trip (one address, immediate offsets; the host pads the bound rows to a multiple of four and the padding's
+// bits are dropped here)
 __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec3 o, vec3 d, bool unitDir) {
-    uint32_t mask = 0;
-    for (int k = 0; k < cnt; ++k) {
-        const float4 b = bounds[k];
-        const vec3 v = o - xyz(b);
-        const float dv = dot(d, v);
-        const float vv = dot(v, v);
-        const float dv2 = dv * dv;
-        const bool lineClear = (vv * (1.0f - kAccelMu) - kAccelDvScale * dv2) > b.w;           // the LINE misses the chunk
-        const bool behind = (dv > 0.0f) && (dv2 * (1.0f - 2e-5f) > b.w + kAccelMu * vv);       // the chunk lies behind the origin
-        if (!(lineClear || behind)) mask |= 1u << k;  // not provably out of reach (a NaN lands here too)
+    const int trips = (cnt + 3) >> 2;  // wave-uniform, 1..8
+    uint32_t rev = 0;
+    for (int g = 0; g < trips; ++g) {
+        const float4 b0 = bounds[4 * g], b1 = bounds[4 * g + 1], b2 = bounds[4 * g + 2], b3 = bounds[4 * g + 3];
+        shiftInChunk(rev, b0, o, d);
+        shiftInChunk(rev, b1, o, d);
+        shiftInChunk(rev, b2, o, d);
+        shiftInChunk(rev, b3, o, d);
     }
-    return unitDir ? mask : ((cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u));
+    const uint32_t all = (cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u);
+    return unitDir ? ((__builtin_bitreverse32(rev) >> (32 - 4 * trips)) & all) : all;
 }
 
 // Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
@@ -705,7 +719,8 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
 // the wave's queue planes that the current pass does not read (tab[plane] = that half of plane `plane`), which is why
 // the caller uses this only for a pass whose other half is free.
 #ifndef PTSS_WARM
-#define PTSS_WARM 8   // 2 ... 16 measured within 2 % of each other
+#define PTSS_WARM 2   // chunks of 16 in kd order (round 2), configs[5] scene at S = 4, same box: 0: 4,571, 1: 4,589, 2: 4,597-4,605,
+                      // 3: 4,585, 4: 4,535, 8: 4,270, 16: 4,189 Mrays/s (round 1, chunks of 8 in Morton order: 2 ... 16 within 2 %)
 #endif
 constexpr int kWarmChunks = PTSS_WARM;
 

@@ -31,7 +31,11 @@ VARIANTS = {
     "stamps": ["PTSS_STAMPS=1"],
     "qhist": ["PTSS_QHIST=1"],
     "norgs": ["PTSS_REGROUP_SHADOW=0"],  # many-sphere scenes: shadow rays walk all their chunks lane by lane
+    "warm0": ["PTSS_WARM=0"],
+    "warm1": ["PTSS_WARM=1"],
     "warm2": ["PTSS_WARM=2"],
+    "warm3": ["PTSS_WARM=3"],
+    "warm4": ["PTSS_WARM=4"],
     "warm16": ["PTSS_WARM=16"],
     "norg": ["PTSS_REGROUP=0"],  # many-sphere scenes: every lane walks its own chunks in the closest hit too
     "ck4": ["PTSS_CHUNK=4"],
