@@ -27,8 +27,10 @@ ray-bounce: 76 B SoA state read + 76 B written) / HIP-event tim
 `valu.issue_frac` = wave-level VALU instructions per launch (SQ_INSTS_VALU, from the committed PMC summary
 profiles/pmc_counters.json, taken with this configuration) / (1,024 SIMDs x 2.4 GHz / 2 cycles x the launch time
 measured in THIS run). `cpu_baseline` times oracle/ (the CPU restatement, OpenMP) on a bounded slice of the same
-workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode (one context);
-`s1_two_shards_two_streams_mrays_per_s` the same frame as two pixel-band shards on two streams of this one GPU.
+workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode, one context with the
+library's own choice of frame lanes (cfg.frameLanes = 0: two ray populations on two streams at 1080p, image and loop guard
+identical to one); `s1_one_lane_mrays_per_s` the same with one lane; `s1_two_shards_two_streams_mrays_per_s` the same
+frame as two pixel-band shard CONTEXTS on two streams (the multi-GPU sharding on one GPU: the loop-guard caveat applies).
 """
 import argparse
 import json
@@ -98,7 +100,7 @@ def pmc_counters(config, samples):
     return None, None
 
 
-def s1_leg(ptss, torch, scene, cfg, shards=1, passes=200, warmup=20):
+def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes=0):
     """The reference's own mode on the same frame: one sample per pixel per generateFrame call (CudaTracer.cu:587-647).
     shards = 1: one context, the reference's semantics to the letter. shards = K > 1: the same frame as K interleaved
     pixel-band shards (cfg.tileWorld = K, the multi-GPU sharding) in THIS process on this one GPU, each on its own stream,
@@ -107,7 +109,8 @@ def s1_leg(ptss, torch, scene, cfg, shards=1, passes=200, warmup=20):
     rs, pix = [], []
     for k in range(shards):
         r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
-                          tile_rank=k, tile_world=shards, band_rows=BAND_ROWS, sync_each_frame=False, samples_per_pass=1)
+                          tile_rank=k, tile_world=shards, band_rows=BAND_ROWS, sync_each_frame=False, samples_per_pass=1,
+                          frame_lanes=frame_lanes)
         r.set_stream(torch.cuda.Stream().cuda_stream if shards > 1 else torch.cuda.current_stream().cuda_stream)
         rs.append(r)
         pix.append(torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda"))
@@ -309,10 +312,12 @@ def main():
                             "the HBM and VALU-issue fractions")
             out["roofline"] = roof
         if world == 1 and not args.no_s1_leg:
-            v, ms = s1_leg(ptss, torch, scene, cfg)
+            v, ms = s1_leg(ptss, torch, scene, cfg)               # the library's own choice of frame lanes (2 at 1080p)
             out["s1_mrays_per_s"] = v
             out["s1_ms_per_pass"] = ms
-            v2, ms2 = s1_leg(ptss, torch, scene, cfg, shards=2)
+            v1, _ = s1_leg(ptss, torch, scene, cfg, frame_lanes=1)  # one ray population on one stream
+            out["s1_one_lane_mrays_per_s"] = v1
+            v2, ms2 = s1_leg(ptss, torch, scene, cfg, shards=2, frame_lanes=1)
             out["s1_two_shards_two_streams_mrays_per_s"] = v2
             out["s1_two_shards_two_streams_ms_per_pass"] = ms2
         if world == 1 and not args.no_cpu_baseline:

@@ -50,6 +50,27 @@ struct EventPair {
 
 }  // namespace
 
+// One ray population of the frame with its own pools, counters and stream (ptss_device.h, "frame lanes"). A context
+// has 1..kMaxLanes of them; with one lane the caller's stream is used and nothing below differs from a single population.
+struct Lane {
+    hipStream_t stream = nullptr;            // own stream (contexts with several lanes only)
+    float* dPool[2] = {nullptr, nullptr};
+    uint32_t* dCounts[2] = {nullptr, nullptr};   // alternate per frame (flushKernel arms the other one)
+    uint32_t* dShardCount0 = nullptr;
+    uint32_t* dLastCounts = nullptr;         // counts of the frame before (flushKernel's copy)
+    uint32_t* dDone = nullptr;               // [kMaxBounces + 1] words: "my counts of bounce b are final" = the frame's tag
+                                             // (stored by this lane's bounce-b kernel as it starts: bounce b - 1 has then finished)
+    hipEvent_t evDone[2] = {nullptr, nullptr};   // end of this lane's frame, by frame parity (several lanes only)
+    uint32_t regionCap = 0;                  // slots per shard region of this lane's pools
+    int maxBlocks = 0;                       // one 256-ray tile per workgroup over this lane's share of the frame
+    // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
+    uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
+    bool haveHint = false;
+    uint32_t* hCounts = nullptr;  // pinned, 4 slots x kCountWords
+    hipEvent_t hintEvent[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hintPending[4] = {false, false, false, false};
+};
+
 struct ptss_context {
     ptss_render_config cfg{};
     hipStream_t stream = nullptr;
@@ -60,19 +81,19 @@ struct ptss_context {
     ptss::SceneLayout layoutAlt{};
     bool sceneInLdsAlt = true;
     bool haveAccel = false, accelActive = false;
-    float* dPool[2] = {nullptr, nullptr};
+    std::vector<Lane> lanes;
+    hipEvent_t evFork = nullptr;            // several lanes: the caller's stream has reached this frame
+    uint32_t frameTag = 0;
+    int countParity = 0;                    // which of a lane's two count buffers the next frame uses
     uint32_t* dRngHome = nullptr;
-    uint32_t* dCounts = nullptr;
-    unsigned long long* dTotal = nullptr;   // [0] ray-bounce total, [1..8] diagnostic phase stamps
+    unsigned long long* dTotal = nullptr;   // [0 .. kMaxLanes) ray-bounce totals per lane, [kMaxLanes .. +8) diagnostic phase stamps,
+                                            // then one word: guard timeouts (must stay 0)
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
     float* dFsum = nullptr;
     uint32_t* dStaged = nullptr;  // S > 1: per-stream sample words of the current pass
     uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
-    uint32_t poolStride = 0, regionCap = 0;  // ray pools: kShards regions of regionCap slots
     uint32_t samples = 1;                    // cfg.samplesPerPass (sample lanes per pixel)
-    uint32_t* dShardCount0 = nullptr;
-    uint32_t* dLastCounts = nullptr;   // counts of the frame before (flushKernel's copy)
     bool cameraDirty = true;           // primary-ray precomputes must be refreshed
     float defaultColor[3] = {0, 0, 0};
     // ProgramData (CudaTracer.h:32-42)
@@ -84,21 +105,18 @@ struct ptss_context {
     bool usePathTracer = true;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
-    int maxBlocks = 0;           // one 256-ray tile per workgroup over the whole local frame
     int gridCap = 0;             // workgroups per shard at most = 16 resident rounds of this scene's bounce kernel (0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
-    // live-count hints: counts[] of a recent frame, read back asynchronously, size the next frames' grids
-    uint32_t hint[ptss::kMaxBounces + 1] = {0};  // per bounce: the fullest shard's live count
-    bool haveHint = false;
-    uint32_t* hCounts = nullptr;  // pinned, 4 slots x kCountWords
-    hipEvent_t hintEvent[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool hintPending[4] = {false, false, false, false};
     unsigned frameIndex = 0;
     // bounce-kernel timing (cfg.timeKernels)
     std::vector<EventPair> evFree, evBusy;
     double kernelMs = 0.0;
     unsigned long long kernelLaunches = 0;
 };
+constexpr int kTotalWords = ptss::kMaxLanes + 8 + 1;
+#ifndef PTSS_LANE_ALWAYS_FORK
+#define PTSS_LANE_ALWAYS_FORK 0   // 1: every frame starts with a fork from the caller's stream (A/B timing only)
+#endif
 
 namespace {
 
@@ -312,34 +330,51 @@ int validateScene(const ptss_scene_desc& s) {
     return PTSS_OK;
 }
 
-ptss::FrameBuffers frameBuffers(const ptss_context* c, ptss_uchar4* pixels, int sample) {
+ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4* pixels, int sample) {
+    const Lane& ln = c->lanes[(size_t)laneIdx];
     ptss::FrameBuffers fb{};
-    fb.pool[0] = c->dPool[0];
-    fb.pool[1] = c->dPool[1];
+    fb.pool[0] = ln.dPool[0];
+    fb.pool[1] = ln.dPool[1];
     fb.rngHome = c->dRngHome;
-    fb.counts = c->dCounts;
-    fb.shardCount0 = c->dShardCount0;
-    fb.lastCounts = c->dLastCounts;
-    fb.totalRayBounces = c->dTotal;
-    fb.stamps = c->dTotal + 1;
+    fb.counts = ln.dCounts[c->countParity];
+    fb.countsNext = ln.dCounts[1 - c->countParity];
+    fb.shardCount0 = ln.dShardCount0;
+    fb.lastCounts = ln.dLastCounts;
+    fb.totalRayBounces = c->dTotal + laneIdx;
+    fb.stamps = c->dTotal + ptss::kMaxLanes;
+    fb.guardTimeouts = reinterpret_cast<uint32_t*>(c->dTotal + ptss::kMaxLanes + 8);
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
     fb.staged = c->dStaged;
     fb.quantTable = reinterpret_cast<const float*>(c->dScene + c->layout.offQuant);
     fb.pixels = pixels;
-    fb.regionCap = c->regionCap;
+    fb.regionCap = ln.regionCap;
     fb.numPixels = c->numPixels;
     fb.plane = c->capacity;
     fb.samples = c->samples;
     fb.firstTiles = c->samples * (c->capacity / ptss::kBlock);
     // The reference stops bouncing once <= 128 rays are live IN THE WHOLE FRAME (CudaTracer.cu:622). A
-    // shard cannot know the frame-wide count without a collective per bounce, so a sharded context
-    // never stops early; the two agree whenever the frame-wide count stays above 128.
+    // shard of a multi-GPU frame cannot know the frame-wide count without a collective per bounce, so a context with
+    // tileWorld > 1 never stops early; the two agree whenever the frame-wide count stays above 128. (The lanes of ONE
+    // context do know each other's counts: the guard is exact for any number of lanes.)
     fb.minLive = c->tile.world > 1 ? 0u : ptss::kMinLiveRays;
     fb.inverseTicks = 1.f / (float)((int)c->samples * (sample + 1));  // CudaTracer.cu:94 (S = 1: 1.f / (ticks + 1))
     fb.defaultColor[0] = c->defaultColor[0];
     fb.defaultColor[1] = c->defaultColor[1];
     fb.defaultColor[2] = c->defaultColor[2];
+    fb.laneIndex = (uint32_t)laneIdx;
+    fb.laneCount = (uint32_t)c->lanes.size();
+    fb.frameRays = c->numPixels * c->samples;
+    fb.numPeers = fb.laneCount - 1;
+    fb.frameTag = c->frameTag;
+    fb.myDone = ln.dDone;
+    uint32_t p = 0;
+    for (size_t k = 0; k < c->lanes.size(); ++k) {
+        if ((int)k == laneIdx) continue;
+        fb.peerCounts[p] = c->lanes[k].dCounts[c->countParity];
+        fb.peerDone[p] = c->lanes[k].dDone;
+        ++p;
+    }
     return fb;
 }
 
@@ -399,6 +434,7 @@ int ptss_default_config(ptss_render_config* cfg) {
     cfg->timeKernels = 0;
     cfg->samplesPerPass = 1;
     cfg->everySphereLoop = 0;
+    cfg->frameLanes = 0;
     return PTSS_OK;
 }
 
@@ -459,19 +495,36 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     const uint32_t gran = ptss::kBlock > 256 ? (uint32_t)ptss::kBlock : 256u;  // pixel planes are whole tiles
     c->capacity = ((c->numPixels + gran - 1) / gran) * gran;
     if (c->capacity == 0) c->capacity = gran;
-    uint32_t shardCount0[ptss::kShards] = {0};
+    // Frame lanes (ptss_device.h): cfg.frameLanes, or by the size of a pass when 0 — launch-shaped passes (a few
+    // resident rounds per launch) gain a fifth from a second lane, wide ones nothing.
+    int numLanes = cfg->frameLanes;
+    if (numLanes < 0 || numLanes > ptss::kMaxLanes) return (delete c, fail(PTSS_EINVAL, "frameLanes must be in [0, 4]"));
     {
-        // bounce 0 walks S sample planes of `capacity` pixels (capacity = numPixels rounded up to a tile)
+        const unsigned long long rays = (unsigned long long)c->numPixels * c->samples;
+        // measured (tools/lanes_bench.py, Mrays/s with 1 / 2 / 3 / 4 lanes): 1920x1080 S = 1 (2.1 M rays per pass) 13,200 /
+        // 14,700-15,400 / 14,300 / 9,700; 3840x2160 1,024 spheres S = 1 (8.3 M) 4,000 / 4,250 / 4,410 / 3,310; 1280x720 S = 1
+        // (0.9 M) 9,150 / 8,350-9,640 / 8,590 / 4,830; 1920x1080 S = 40 (83 M) 17,000 / 17,150 / 16,970 / 16,620. Four lanes
+        // (five streams with the caller's) share hardware queues and serialise.
+        if (numLanes == 0) numLanes = (rays >= (1ull << 20) && rays <= (1ull << 24)) ? 2 : 1;
+    }
+    c->lanes.resize((size_t)numLanes);
+    uint32_t shardCount0[ptss::kMaxLanes][ptss::kShards] = {{0}};
+    {
+        // bounce 0 walks S sample planes of `capacity` pixels (capacity = numPixels rounded up to a tile); tile t belongs
+        // to shard t % kShards and to round t / kShards, round R to lane R % numLanes
         const uint32_t tilesPerPlane = c->capacity / ptss::kBlock;
         const uint32_t tiles = tilesPerPlane * c->samples;
-        const uint32_t tilesPerShard = (tiles + ptss::kShards - 1) / ptss::kShards;
-        c->regionCap = (tilesPerShard ? tilesPerShard : 1) * ptss::kBlock;
-        c->poolStride = c->regionCap * ptss::kShards;
+        const uint32_t rounds = (tiles + ptss::kShards - 1) / ptss::kShards;
+        for (int k = 0; k < numLanes; ++k) {
+            const uint32_t laneRounds = (rounds + (uint32_t)numLanes - 1 - (uint32_t)k) / (uint32_t)numLanes;
+            c->lanes[(size_t)k].regionCap = (laneRounds ? laneRounds : 1) * ptss::kBlock;
+            c->lanes[(size_t)k].maxBlocks = (int)(c->lanes[(size_t)k].regionCap / ptss::kBlock) * ptss::kShards;
+        }
         for (uint32_t t = 0; t < tiles; ++t) {
             const uint32_t first = (t % tilesPerPlane) * ptss::kBlock;  // first pixel of the tile inside its plane
             uint32_t cnt = 0;
             if (first < c->numPixels) cnt = c->numPixels - first < (uint32_t)ptss::kBlock ? c->numPixels - first : (uint32_t)ptss::kBlock;
-            shardCount0[t % ptss::kShards] += cnt;
+            shardCount0[(t / ptss::kShards) % (uint32_t)numLanes][t % ptss::kShards] += cnt;
         }
     }
 
@@ -502,20 +555,35 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(hipMalloc(&c->dSceneAlt, blobAlt.size() * sizeof(float4)));
         CREATE_TRY(hipMemcpy(c->dSceneAlt, blobAlt.data(), blobAlt.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
-    const size_t poolBytes = (size_t)ptss::kRayPlanes * c->poolStride * sizeof(float);
-    CREATE_TRY(hipMalloc(&c->dPool[0], poolBytes));
-    CREATE_TRY(hipMalloc(&c->dPool[1], poolBytes));
     CREATE_TRY(hipMalloc(&c->dRngHome, (size_t)ptss::kHomeWords * c->capacity * c->samples * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&c->dCounts, ptss::kCountWords * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(c->dCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&c->dLastCounts, ptss::kCountWords * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(c->dLastCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
-    for (int s = 0; s < ptss::kShards; ++s)  // arm bounce 0 of the first frame (flushKernel re-arms every later one)
-        CREATE_TRY(hipMemcpy(c->dCounts + ptss::countIndex(0, s), &shardCount0[s], sizeof(uint32_t), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(&c->dShardCount0, sizeof(shardCount0)));
-    CREATE_TRY(hipMemcpy(c->dShardCount0, shardCount0, sizeof(shardCount0), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(&c->dTotal, 9 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(c->dTotal, 0, 9 * sizeof(unsigned long long)));
+    for (int k = 0; k < numLanes; ++k) {
+        Lane& ln = c->lanes[(size_t)k];
+        const size_t poolBytes = (size_t)ptss::kRayPlanes * ln.regionCap * ptss::kShards * sizeof(float);
+        CREATE_TRY(hipMalloc(&ln.dPool[0], poolBytes));
+        CREATE_TRY(hipMalloc(&ln.dPool[1], poolBytes));
+        for (int b = 0; b < 2; ++b) {
+            CREATE_TRY(hipMalloc(&ln.dCounts[b], ptss::kCountWords * sizeof(uint32_t)));
+            CREATE_TRY(hipMemset(ln.dCounts[b], 0, ptss::kCountWords * sizeof(uint32_t)));
+        }
+        CREATE_TRY(hipMalloc(&ln.dLastCounts, ptss::kCountWords * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(ln.dLastCounts, 0, ptss::kCountWords * sizeof(uint32_t)));
+        for (int s = 0; s < ptss::kShards; ++s)  // arm bounce 0 of the first frame (flushKernel arms every later one)
+            CREATE_TRY(hipMemcpy(ln.dCounts[0] + ptss::countIndex(0, s), &shardCount0[k][s], sizeof(uint32_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&ln.dShardCount0, sizeof(shardCount0[k])));
+        CREATE_TRY(hipMemcpy(ln.dShardCount0, shardCount0[k], sizeof(shardCount0[k]), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&ln.dDone, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(ln.dDone, 0, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+        if (numLanes > 1) {
+            CREATE_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            CREATE_TRY(hipEventCreateWithFlags(&ln.evDone[0], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&ln.evDone[1], hipEventDisableTiming));
+        }
+        CREATE_TRY(hipHostMalloc(&ln.hCounts, 4 * ptss::kCountWords * sizeof(uint32_t), hipHostMallocDefault));
+        for (int q = 0; q < 4; ++q) CREATE_TRY(hipEventCreateWithFlags(&ln.hintEvent[q], hipEventDisableTiming));
+    }
+    if (numLanes > 1) CREATE_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    CREATE_TRY(hipMalloc(&c->dTotal, kTotalWords * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(c->dTotal, 0, kTotalWords * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&c->dAccumOwned, (size_t)3 * c->capacity * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->dAccumOwned, 0, (size_t)3 * c->capacity * sizeof(uint32_t)));
     c->dAccum = c->dAccumOwned;
@@ -550,7 +618,6 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     // profiles/README.md r01.)
     c->sceneInLds = sceneFitsLds;
     c->sceneInLdsAlt = sceneFitsLdsAlt;
-    c->maxBlocks = (int)(c->regionCap / ptss::kBlock) * ptss::kShards;  // one tile per workgroup, every shard
     {
         // Launches wider than 16 resident rounds stop growing: a workgroup then walks several tiles and stages the scene
         // into LDS once for all of them. One round = CUs x workgroups per CU of THIS scene's bounce kernel (LDS image and
@@ -568,8 +635,6 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         if (const char* e = getenv("PTSS_GRID_CAP")) c->gridCap = atoi(e);
 #endif
     }
-    CREATE_TRY(hipHostMalloc(&c->hCounts, 4 * ptss::kCountWords * sizeof(uint32_t), hipHostMallocDefault));
-    for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreateWithFlags(&c->hintEvent[k], hipEventDisableTiming));
 #undef CREATE_TRY
 
     *out = c;
@@ -585,19 +650,27 @@ int ptss_destroy(ptss_context* c) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
-    for (int k = 0; k < 4; ++k)
-        if (c->hintEvent[k]) (void)hipEventDestroy(c->hintEvent[k]);
-    if (c->hCounts) (void)hipHostFree(c->hCounts);
+    for (Lane& ln : c->lanes) {
+        for (int q = 0; q < 4; ++q)
+            if (ln.hintEvent[q]) (void)hipEventDestroy(ln.hintEvent[q]);
+        if (ln.hCounts) (void)hipHostFree(ln.hCounts);
+        (void)hipFree(ln.dDone);
+        if (ln.evDone[0]) (void)hipEventDestroy(ln.evDone[0]);
+        if (ln.evDone[1]) (void)hipEventDestroy(ln.evDone[1]);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+        (void)hipFree(ln.dPool[0]);
+        (void)hipFree(ln.dPool[1]);
+        (void)hipFree(ln.dCounts[0]);
+        (void)hipFree(ln.dCounts[1]);
+        (void)hipFree(ln.dShardCount0);
+        (void)hipFree(ln.dLastCounts);
+    }
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     (void)hipFree(c->dScene);
     (void)hipFree(c->dSceneAlt);
-    (void)hipFree(c->dPool[0]);
-    (void)hipFree(c->dPool[1]);
     (void)hipFree(c->dRngHome);
-    (void)hipFree(c->dCounts);
-    (void)hipFree(c->dShardCount0);
-    (void)hipFree(c->dLastCounts);
     (void)hipFree(c->dTotal);
     (void)hipFree(c->dAccumOwned);
     (void)hipFree(c->dFsum);
@@ -629,13 +702,18 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             c->cameraDirty = true;
         }
     }
+    bool forkNeeded = false;
     if (c->resetTicksThisFrame) {  // CudaTracer.cu:602-608
+        forkNeeded = true;
         c->lastResetTick = ticks;
-        HIP_TRY(ptss::launchClear(st, frameBuffers(c, pixels, 0)));
+        HIP_TRY(ptss::launchClear(st, frameBuffers(c, 0, pixels, 0)));
         c->resetTicksThisFrame = false;
     }
     const int sample = ticks - c->lastResetTick;
-    const ptss::FrameBuffers fb = frameBuffers(c, pixels, sample);
+    const int K = (int)c->lanes.size();
+    c->frameTag += 1;
+    ptss::FrameBuffers fbs[ptss::kMaxLanes];
+    for (int k = 0; k < K; ++k) fbs[k] = frameBuffers(c, k, pixels, sample);
 
     if (c->cfg.syncEachFrame) HIP_TRY(hipEventRecord(c->evStart, st));  // :611
 
@@ -648,76 +726,108 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     eye.invW = 1.0f / c->tile.width;
     eye.invH = 1.0f / c->tile.height;
     if (c->cameraDirty) {  // origin-only parts of the primary-ray tests (computeEyeRaysKernel :614 itself is fused into bounce 0)
+        forkNeeded = true;
         HIP_TRY(ptss::launchPrimaryPrep(st, c->dScene, c->layout, c->camera.position));
         c->cameraDirty = false;
     }
 
-    // harvest the newest finished live-count readback (never blocks)
-    for (int k = 0; k < 4; ++k) {
-        if (!c->hintPending[k]) continue;
-        if (hipEventQuery(c->hintEvent[k]) == hipSuccess) {
-            const uint32_t* src = c->hCounts + (size_t)k * ptss::kCountWords;
-            for (int b = 0; b <= ptss::kMaxBounces; ++b) {
-                uint32_t mx = 0;
-                for (int s = 0; s < ptss::kShards; ++s) {
-                    const uint32_t v = src[ptss::countIndex(b, s)];
-                    if (v > mx) mx = v;
+    // harvest the newest finished live-count readbacks (never blocks)
+    for (Lane& ln : c->lanes)
+        for (int q = 0; q < 4; ++q) {
+            if (!ln.hintPending[q]) continue;
+            if (hipEventQuery(ln.hintEvent[q]) == hipSuccess) {
+                const uint32_t* src = ln.hCounts + (size_t)q * ptss::kCountWords;
+                for (int b = 0; b <= ptss::kMaxBounces; ++b) {
+                    uint32_t mx = 0;
+                    for (int s = 0; s < ptss::kShards; ++s) {
+                        const uint32_t v = src[ptss::countIndex(b, s)];
+                        if (v > mx) mx = v;
+                    }
+                    ln.hint[b] = mx;
                 }
-                c->hint[b] = mx;
+                ln.haveHint = true;
+                ln.hintPending[q] = false;
             }
-            c->haveHint = true;
-            c->hintPending[k] = false;
         }
-    }
     (void)hipGetLastError();
 
+    // Several lanes: each runs on its own stream, forked from the caller's here and joined into it below; their
+    // launches are issued round-robin, bounce by bounce, so that the streams advance together.
+    // The fork is needed only when the caller's stream did something the lanes depend on (the clear of a reset, the
+    // camera precomputes) — otherwise a lane's next frame depends on nothing but its own previous one, and the lanes run
+    // on, frame after frame, while the caller's stream merely waits for each frame's end (the join below).
+    if (K > 1 && (forkNeeded || c->frameIndex == 0 || PTSS_LANE_ALWAYS_FORK)) {
+        HIP_TRY(hipEventRecord(c->evFork, st));
+        for (Lane& ln : c->lanes) HIP_TRY(hipStreamWaitEvent(ln.stream, c->evFork, 0));
+    }
     if (c->cfg.timeKernels) drainKernelEvents(c, false);
     for (int i = 0; i < numIterations; ++i) {  // :622-633, guard evaluated on the device
-        // grid: one tile per workgroup for the expected live count (+1.5 %), never more than the frame;
-        // the kernel grid-strides, so a low hint costs time, not correctness
-        int blocks = c->maxBlocks;
-        if (i > 0 && c->haveHint) {
-            // tiles for the fullest shard (+1.5 %), times kShards (workgroup b serves shard b % kShards)
-            const unsigned long long tilesPerShard = ((unsigned long long)c->hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
-            const unsigned long long want = tilesPerShard * ptss::kShards;
-            if (want < (unsigned long long)blocks) blocks = (int)want;
-        }
-        // launches wider than 16 resident rounds stop growing (gridCap, ptss_create)
-        if (c->gridCap > 0 && c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
-        EventPair ev{nullptr, nullptr};
-        if (c->cfg.timeKernels) {
-            if (c->evFree.empty()) {
-                if (c->evBusy.size() >= 4096) drainKernelEvents(c, true);
+        for (int k = 0; k < K; ++k) {
+            Lane& ln = c->lanes[(size_t)k];
+            hipStream_t ls = K > 1 ? ln.stream : st;
+            // grid: one tile per workgroup for the expected live count (+1.5 %), never more than the lane's share of the
+            // frame; the kernel grid-strides, so a low hint costs time, not correctness
+            int blocks = ln.maxBlocks;
+            if (i > 0 && ln.haveHint) {
+                // tiles for the fullest shard (+1.5 %), times kShards (workgroup b serves shard b % kShards)
+                const unsigned long long tilesPerShard = ((unsigned long long)ln.hint[i] * 65 / 64 + ptss::kBlock) / ptss::kBlock + 1;
+                const unsigned long long want = tilesPerShard * ptss::kShards;
+                if (want < (unsigned long long)blocks) blocks = (int)want;
+            }
+            // launches wider than 16 resident rounds stop growing (gridCap, ptss_create)
+            if (c->gridCap > 0 && c->gridCap * ptss::kShards < blocks) blocks = c->gridCap * ptss::kShards;
+            EventPair ev{nullptr, nullptr};
+            if (c->cfg.timeKernels) {
                 if (c->evFree.empty()) {
-                    HIP_TRY(hipEventCreate(&ev.a));
-                    HIP_TRY(hipEventCreate(&ev.b));
+                    if (c->evBusy.size() >= 4096) drainKernelEvents(c, true);
+                    if (c->evFree.empty()) {
+                        HIP_TRY(hipEventCreate(&ev.a));
+                        HIP_TRY(hipEventCreate(&ev.b));
+                    }
                 }
+                if (!ev.a) {
+                    ev = c->evFree.back();
+                    c->evFree.pop_back();
+                }
+                HIP_TRY(hipEventRecord(ev.a, ls));
             }
-            if (!ev.a) {
-                ev = c->evFree.back();
-                c->evFree.pop_back();
+            HIP_TRY(ptss::launchBounce(ls, fbs[k], c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks, c->tile, eye));
+            if (c->cfg.timeKernels) {
+                HIP_TRY(hipEventRecord(ev.b, ls));
+                c->evBusy.push_back(ev);
             }
-            HIP_TRY(hipEventRecord(ev.a, st));
-        }
-        HIP_TRY(ptss::launchBounce(st, fb, c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks, c->tile, eye));
-        if (c->cfg.timeKernels) {
-            HIP_TRY(hipEventRecord(ev.b, st));
-            c->evBusy.push_back(ev);
+            // Lanes 1..: "my counts of bounce i + 1 are final", behind the kernel that made them — for the lanes whose
+            // bounce i + 1 is enqueued before this lane's (they may share its hardware queue and cannot wait for this
+            // lane's own bounce-(i + 1) kernel to start; lane 0 is first in every round and is waited for that way only).
+            if (k > 0 && i + 1 < numIterations) HIP_TRY(ptss::launchSignal(ls, ln.dDone + (i + 1), c->frameTag));
         }
     }
-    HIP_TRY(ptss::launchFlush(st, fb, numIterations));  // :637
-    if (c->samples > 1) HIP_TRY(ptss::launchDisplay(st, fb));  // S > 1: add the pass's staged samples, then the display value
-
-    // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
-    if (!c->haveHint || (c->frameIndex & 7u) == 0) {
-        const int k = (int)((c->frameIndex >> 3) & 3u);
-        if (!c->hintPending[k]) {
-            HIP_TRY(hipMemcpyAsync(c->hCounts + (size_t)k * ptss::kCountWords, c->dLastCounts,
-                                   ptss::kCountWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipEventRecord(c->hintEvent[k], st));
-            c->hintPending[k] = true;
+    for (int k = 0; k < K; ++k) {
+        Lane& ln = c->lanes[(size_t)k];
+        hipStream_t ls = K > 1 ? ln.stream : st;
+        // flushKernel re-arms the count buffer of the frame BEFORE this one for the frame after it; a peer lane may still
+        // be reading that buffer (it can run one frame behind), so the flush waits for every peer's previous frame
+        if (K > 1 && c->frameIndex > 0)
+            for (int j = 0; j < K; ++j)
+                if (j != k) HIP_TRY(hipStreamWaitEvent(ls, c->lanes[(size_t)j].evDone[(c->frameIndex - 1) & 1u], 0));
+        HIP_TRY(ptss::launchFlush(ls, fbs[k], numIterations));  // :637
+        // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
+        if (!ln.haveHint || (c->frameIndex & 7u) == 0) {
+            const int q = (int)((c->frameIndex >> 3) & 3u);
+            if (!ln.hintPending[q]) {
+                HIP_TRY(hipMemcpyAsync(ln.hCounts + (size_t)q * ptss::kCountWords, ln.dLastCounts, ptss::kCountWords * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, ls));
+                HIP_TRY(hipEventRecord(ln.hintEvent[q], ls));
+                ln.hintPending[q] = true;
+            }
+        }
+        if (K > 1) {  // the join: the caller's stream is ordered behind every lane's frame (the lanes themselves run on)
+            HIP_TRY(hipEventRecord(ln.evDone[c->frameIndex & 1u], ls));
+            HIP_TRY(hipStreamWaitEvent(st, ln.evDone[c->frameIndex & 1u], 0));
         }
     }
+    if (c->samples > 1) HIP_TRY(ptss::launchDisplay(st, fbs[0]));  // S > 1: add the pass's staged samples, then the display value
+    c->countParity ^= 1;
     c->frameIndex++;
 
     if (c->cfg.syncEachFrame) {  // :639-642
@@ -888,14 +998,17 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
     if (!c || !out || !n) return fail(PTSS_EINVAL, "null argument");
     const int numIterations = c->usePathTracer ? (int)c->maxIterations : 1;
     if (cap < numIterations) return fail(PTSS_ERANGE, "out[] too small");
-    std::vector<uint32_t> raw(ptss::kCountWords);
+    std::vector<uint32_t> raw(ptss::kCountWords), sum(ptss::kCountWords, 0u);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(raw.data(), c->dLastCounts, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (const Lane& ln : c->lanes) {  // the frame's count = its lanes' counts added up
+        HIP_TRY(hipMemcpy(raw.data(), ln.dLastCounts, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < raw.size(); ++k) sum[k] += raw[k];
+    }
     // a bounce whose input is <= 128 rays did not run (CudaTracer.cu:622): report 0 from there on
     bool stopped = false;
     for (int i = 0; i < numIterations; ++i) {
         uint32_t total = 0;
-        for (int s = 0; s < ptss::kShards; ++s) total += raw[ptss::countIndex(i, s)];
+        for (int s = 0; s < ptss::kShards; ++s) total += sum[ptss::countIndex(i, s)];
         if (total <= (c->tile.world > 1 ? 0u : ptss::kMinLiveRays)) stopped = true;
         out[i] = stopped ? 0u : total;
     }
@@ -906,7 +1019,25 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
 int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
     if (!c || !out) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->dTotal, sizeof(*out), hipMemcpyDeviceToHost));
+    unsigned long long perLane[ptss::kMaxLanes];
+    HIP_TRY(hipMemcpy(perLane, c->dTotal, sizeof(perLane), hipMemcpyDeviceToHost));
+    *out = 0;
+    for (size_t k = 0; k < c->lanes.size(); ++k) *out += perLane[k];
+    return PTSS_OK;
+}
+
+int ptss_guard_timeouts(ptss_context* c, unsigned int* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpy(&v, c->dTotal + ptss::kMaxLanes + 8, sizeof(v), hipMemcpyDeviceToHost));
+    *out = v;
+    return PTSS_OK;
+}
+
+int ptss_frame_lanes(const ptss_context* c, int* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = (int)c->lanes.size();
     return PTSS_OK;
 }
 
@@ -917,7 +1048,7 @@ int ptss_debug_phase_cycles(ptss_context* c, unsigned long long* out8) {
     HIP_TRY(ptss::readCandidateHist(out8));
     return PTSS_OK;
 #endif
-    HIP_TRY(hipMemcpy(out8, c->dTotal + 1, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out8, c->dTotal + ptss::kMaxLanes, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTSS_OK;
 }
 

@@ -165,10 +165,28 @@ struct EyeParams {  // computeEyeRay constants evaluated once on the host with p
     float invW, invH;
 };
 
+// ---- frame lanes: one frame traced as K independent ray populations on K streams of one device -----------------
+// A launch-shaped pass (one sample per pixel: ten kernels of 30-90 us) loses a fifth of its time to the ramp and tail of
+// launches only a few resident rounds wide. Lane k owns the bounce-0 tiles of rounds R with R % K == k (round R = tiles
+// 16 R .. 16 R + 15, one per shard), its own pools, counters and stream; all per-pixel state (random streams,
+// accumulator, display) is shared — lanes touch disjoint pixels. The tail of one lane's launch overlaps the other lanes'
+// kernels. The loop guard `numRays > 128` (CudaTracer.cu:622) stays a WHOLE-FRAME quantity: a lane whose own count is
+// above 128 knows the frame's is; only a lane holding <= 128 rays (then at most one workgroup per shard has work) waits
+// for its peers' counts of that bounce and adds them up. A lane publishes "my counts of bounce b are final" itself: the
+// first thing its bounce-b kernel does is store the frame's tag into done[b] — the stream is in order, so bounce b - 1 has
+// finished when bounce b starts. That serves the peers whose own bounce-b kernel was enqueued later; a peer enqueued
+// EARLIER may share a hardware queue with this lane and must not wait for a kernel behind it, so lanes 1.. also publish
+// the word from a one-thread kernel enqueued right behind bounce b - 1 (in host order before any lane's bounce b). (A
+// stream-ordered hipStreamWriteValue32 after every kernel of every lane cost 9 %, a one-thread kernel after each 4 %; lane
+// 0 needs none.) So the image is the one-lane image, exactly, for every K, whatever the streams' queue mapping.
+constexpr int kMaxLanes = 4;
+
 struct FrameBuffers {
     float* pool[2];          // ray pools (ping-pong), kRayPlanes planes each
     uint32_t* rngHome;       // kHomeWords words per local pixel: where a pixel's stream rests between paths
-    uint32_t* counts;        // counts[countIndex(b, s)]: rays of shard s entering bounce b of the current frame
+    uint32_t* counts;        // counts[countIndex(b, s)]: rays of shard s entering bounce b of the current frame (two buffers
+                             // alternate per frame, so that a peer lane can still read this frame's counts after flushKernel)
+    uint32_t* countsNext;    // the other buffer: flushKernel arms it for the next frame
     const uint32_t* shardCount0;  // [kShards] pixels per shard (constant per context): counts of bounce 0
     uint32_t* lastCounts;    // the previous frame's counts (copied by flushKernel before it re-arms `counts`)
     unsigned long long* totalRayBounces;
@@ -187,6 +205,15 @@ struct FrameBuffers {
                              // 0 in a sharded context (the guard is a whole-frame quantity; DESIGN.md "Sharding")
     float inverseTicks;      // 1.f / (ticks - lastResetTick + 1)
     float defaultColor[3];
+    // frame lanes (laneCount = 1: everything below is inert)
+    uint32_t laneIndex, laneCount;
+    uint32_t frameRays;              // rays all lanes together start a pass with (numPixels x samples): bounce 0's guard
+    uint32_t numPeers;               // laneCount - 1
+    uint32_t frameTag;               // value the peers' `done` words carry for the current frame
+    const uint32_t* peerCounts[kMaxLanes - 1];        // the peers' counts[] of the current frame
+    const volatile uint32_t* peerDone[kMaxLanes - 1]; // peerDone[p][b] == frameTag: peer p's counts[b] are final
+    uint32_t* myDone;                // this lane's own words
+    uint32_t* guardTimeouts;         // incremented if a peer's word never arrived (must stay 0; ptss_generate_frame reports it)
 };
 
 // ---- launchers (ptss_kernels.hip) --------------------------------------------------------------
@@ -198,7 +225,8 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
                         bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
-hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);
+hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);  // one per lane
+hipError_t launchSignal(hipStream_t st, uint32_t* word, uint32_t value);
 int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool accel);
 
 }  // namespace ptss

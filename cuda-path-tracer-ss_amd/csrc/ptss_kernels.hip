@@ -879,6 +879,9 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
             }
         }
 #endif
+#if PTSS_ABLATE & 16   // timing only: at most two candidates per lane (what perfect balancing of the candidate loop could save)
+        mask = (mask & -mask) | ((mask & (mask - 1)) & -(mask & (mask - 1)));
+#endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -970,6 +973,9 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
                 atomicAdd(&g_chist[7], (unsigned long long)__popcll(__ballot(live)));
             }
         }
+#endif
+#if PTSS_ABLATE & 16
+        mask = (mask & -mask) | ((mask & (mask - 1)) & -(mask & (mask - 1)));
 #endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
@@ -1299,6 +1305,29 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 #define PTSS_STAMP_FLUSH() do {} while (0)
 #endif
 
+// ---- the loop guard with frame lanes (FrameBuffers, "frame lanes"): the frame's live count of bounce b when this lane's
+// own count `own` is not above the threshold. Waits (bounded) for each peer's "counts of bounce b are final" word, then
+// adds the peers' sixteen shard counters. Called by at most one workgroup per shard of a lane that holds <= 128 rays.
+__device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int bounce, uint32_t own) {
+    uint32_t total = own;
+    for (uint32_t p = 0; p < fb.numPeers; ++p) {
+        uint32_t spins = 0;
+        // (>=, wrap-safe: lanes may run up to one frame apart, and the peer stores a newer tag over this frame's; its counts
+        // of THIS frame stay intact meanwhile — they live in the buffer its flushKernel re-arms only after this lane's frame)
+        while ((int32_t)(__hip_atomic_load(const_cast<const uint32_t*>(fb.peerDone[p]) + bounce, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
+                         fb.frameTag) < 0) {
+            __builtin_amdgcn_s_sleep(64);
+            if (++spins > (1u << 22)) {  // ~ seconds: a peer stream that never runs; do not hang the device
+                if (threadIdx.x == 0) atomicAdd(fb.guardTimeouts, 1u);
+                break;
+            }
+        }
+        for (int s = 0; s < kShards; ++s)
+            total += __hip_atomic_load(fb.peerCounts[p] + countIndex(bounce, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return total;
+}
+
 // ---- LDS work area behind the scene image -----------------------------------------------------
 // block: [0..kWaves) wave survivor totals, [8] block base in the output region
 // per wave: the shadow-ray queue of one NEE round (kNeeLights lights x 64 lanes):
@@ -1415,11 +1444,23 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
                                                                       SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
     extern __shared__ float4 lds[];
     const uint32_t shard = blockIdx.x % kShards;
-    const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays
-    if (n <= fb.minLive) {  // loop guard, CudaTracer.cu:622, on the FRAME's live count (device-side; every
-        uint32_t liveTotal = 0;  // workgroup reaches the same verdict). Only a nearly empty shard has to add up.
-        for (int s = 0; s < kShards; ++s) liveTotal += fb.counts[countIndex(bounce, s)];
-        if (liveTotal <= fb.minLive) return;
+    // frame lanes: this kernel runs, so this lane's bounce - 1 has finished — its counts of `bounce` are final; tell the
+    // peers BEFORE deciding anything (two lanes that both hold <= 128 rays wait for each other's word below). Peers whose
+    // kernel of this bounce was enqueued AFTER this one rely on this store; the others get the word from a signalKernel
+    // behind this lane's previous bounce (ptss_generate_frame) — a waiting kernel must never depend on a kernel that may
+    // sit behind it in a shared hardware queue.
+    if (fb.numPeers != 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(fb.myDone + bounce, fb.frameTag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
+    if constexpr (kFirst) {
+        if (fb.frameRays <= fb.minLive) return;  // loop guard, CudaTracer.cu:622: the frame starts with <= 128 rays
+    } else {
+        if (n == 0) return;  // nothing of this shard reached this bounce (whatever the guard says)
+        if (n <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
+            uint32_t own = 0;   // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
+            for (int s = 0; s < kShards; ++s) own += fb.counts[countIndex(bounce, s)];
+            if (own <= fb.minLive && frameLiveCount(fb, bounce, own) <= fb.minLive) return;
+        }
     }
 
     const uint32_t lane = __lane_id();
@@ -1448,13 +1489,15 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
     // bounce 0 walks the FRAME's tiles (S sample planes of fb.plane pixels; tile t belongs to shard t % kShards),
     // every later bounce walks the shard's compacted region
-    const uint32_t span = kFirst ? ((fb.firstTiles + kShards - 1 - shard) / kShards) * kBlock : n;
+    // (with frame lanes: round R of the frame belongs to lane R % laneCount, whose round R / laneCount it is)
+    const uint32_t roundsOfShard = (fb.firstTiles + kShards - 1 - shard) / kShards;
+    const uint32_t span = kFirst ? ((roundsOfShard + fb.laneCount - 1 - fb.laneIndex) / fb.laneCount) * kBlock : n;
     for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock) {
         const uint32_t i = base + threadIdx.x;
         uint32_t firstPixel = 0, firstLane = 0;
         bool valid = i < n;
         if constexpr (kFirst) {
-            const uint32_t start = ((base / kBlock) * kShards + shard) * kBlock;  // frame tile -> first population index
+            const uint32_t start = (((base / kBlock) * fb.laneCount + fb.laneIndex) * kShards + shard) * kBlock;  // frame tile -> first population index
             firstLane = start / fb.plane;                                         // wave-uniform
             firstPixel = start - firstLane * fb.plane + threadIdx.x;
             valid = firstPixel < fb.numPixels;
@@ -1770,28 +1813,36 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
 // shards together), and add this frame's ray-bounce total to the running counter.
 __global__ void flushKernel(FrameBuffers fb, int numBounces) {
     __shared__ uint32_t totals[kMaxBounces + 1];
+    __shared__ int stopShared;
     for (int b = threadIdx.x; b <= numBounces; b += blockDim.x) {
         uint32_t total = 0;
         for (int s = 0; s < kShards; ++s) total += fb.counts[countIndex(b, s)];
-        totals[b] = total;
+        totals[b] = total;  // this lane's rays entering bounce b
     }
     __syncthreads();
-    int stop = numBounces;
-    unsigned long long sum = 0;
-    for (int b = 0; b < numBounces; ++b) {
-        if (totals[b] <= fb.minLive) {
-            stop = b;
-            break;
+    if (threadIdx.x == 0) {  // where did the frame's loop guard stop? (the bounce kernels decided the same way)
+        int stop = numBounces;
+        unsigned long long sum = 0;
+        for (int b = 0; b < numBounces; ++b) {
+            uint32_t frame = totals[b];
+            if (frame <= fb.minLive) frame = (b == 0) ? fb.frameRays : frameLiveCount(fb, b, frame);
+            if (frame <= fb.minLive) {
+                stop = b;
+                break;
+            }
+            sum += totals[b];
         }
-        sum += totals[b];
+        *fb.totalRayBounces += sum;  // this lane's slot
+        stopShared = stop;
     }
-    if (threadIdx.x == 0) *fb.totalRayBounces += sum;
+    __syncthreads();
+    const int stop = stopShared;
     const uint32_t i = threadIdx.x;
     if (stop == 0) {
-        // Not even bounce 0 ran (<= 128 pixels in the frame). Eye rays are made inside bounce 0, so there are
+        // Not even bounce 0 ran (<= 128 rays in the frame). Eye rays are made inside bounce 0, so there are
         // none in the pool: do what computeEyeRaysKernel + writeToPixelsKernel would have done to each pixel —
-        // two jitter draws, then a sample of radiance 0.
-        if (i < fb.numPixels)
+        // two jitter draws, then a sample of radiance 0. (Lane 0 does it for the whole frame.)
+        if (fb.laneIndex == 0 && i < fb.numPixels)
             for (uint32_t l = 0; l < fb.samples; ++l) {
                 RayRegs ray;
                 loadHome(fb.rngHome, l * fb.plane + i, ray.rng);
@@ -1801,11 +1852,11 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
                 ray.pix = i | (l << kLaneShift);
                 finishPath(fb, ray, fb.quantTable);
             }
-    } else if (totals[stop] != 0) {  // otherwise the last bounce ran: nothing left alive
+    } else if (stop < numBounces && totals[stop] != 0) {  // the guard left this lane's rays alive: writeToPixelsKernel for them
         for (int s = 0; s < kShards; ++s) {
             // n <= 128 = blockDim.x here by the guard that stopped the loop; clamped all the same, and a slot whose pixel
             // or sample lane is out of range is skipped rather than written through: a stale slot must never be able to
-            // fault the device (a GPU memory fault aborts the calling process — DESIGN.md §4c, the round-1 abort)
+            // fault the device (a GPU memory fault aborts the calling process — DESIGN.md §4a, the round-1 abort)
             uint32_t n = fb.counts[countIndex(stop, s)];
             n = n < blockDim.x ? n : blockDim.x;
             if (i < n) {
@@ -1815,13 +1866,15 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
             }
         }
     }
-    // keep this frame's counters for the host (live counts, grid hints), and re-arm them for the next frame:
-    // bounce 0 = the shard's pixels, every later bounce 0
+    // keep this frame's counters for the host (live counts, grid hints) and arm the OTHER buffer for the next frame:
+    // bounce 0 = the shard's pixels, every later bounce 0. This frame's buffer stays as it is: a peer lane may still read it.
     __syncthreads();
-    for (int k = threadIdx.x; k < (numBounces + 1) * kShards; k += blockDim.x) {
+    // (every bounce slot, not just this frame's: the other buffer still holds the counts of two frames ago, and the
+    // bounce count may change between frames — ptss_set_mode, ptss_set_max_iterations)
+    for (int k = threadIdx.x; k < (kMaxBounces + 1) * kShards; k += blockDim.x) {
         const int b = k / kShards, s = k % kShards;
-        fb.lastCounts[countIndex(b, s)] = fb.counts[countIndex(b, s)];
-        fb.counts[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
+        fb.lastCounts[countIndex(b, s)] = (b <= numBounces) ? fb.counts[countIndex(b, s)] : 0u;
+        fb.countsNext[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
     }
 }
 
@@ -1883,6 +1936,13 @@ hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sc
     if (isFirst) { if (isLast) PTSS_GO(true, false, true); else PTSS_GO(false, false, true); }
     if (isLast) PTSS_GO(true, false, false); else PTSS_GO(false, false, false);
 #undef PTSS_GO
+}
+
+// "this lane's counts of bounce b are final", published behind the kernel that made them (see ptss_generate_frame for who needs it)
+__global__ void signalKernel(uint32_t* word, uint32_t value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+hipError_t launchSignal(hipStream_t st, uint32_t* word, uint32_t value) {
+    hipLaunchKernelGGL(signalKernel, dim3(1), dim3(1), 0, st, word, value);
+    return hipGetLastError();
 }
 
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {

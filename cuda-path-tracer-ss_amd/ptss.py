@@ -32,7 +32,7 @@ class RenderConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("seed", C.c_ulonglong), ("maxIterations", C.c_uint),
                 ("device", C.c_int), ("tileRank", C.c_int), ("tileWorld", C.c_int), ("bandRows", C.c_int),
                 ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int),
-                ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int)]
+                ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int), ("frameLanes", C.c_int)]
 
 
 _host = None
@@ -98,6 +98,8 @@ def device_lib():
         L.ptss_samples_since_reset.argtypes = [vp, C.POINTER(C.c_int)]
         L.ptss_live_counts.argtypes = [vp, _u32p, C.c_int, C.POINTER(C.c_int)]
         L.ptss_total_ray_bounces.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        L.ptss_frame_lanes.argtypes = [vp, C.POINTER(C.c_int)]
+        L.ptss_guard_timeouts.argtypes = [vp, C.POINTER(C.c_uint)]
         L.ptss_bounce_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
         L.ptss_error_string.argtypes = [C.c_int]
         L.ptss_error_string.restype = C.c_char_p
@@ -198,7 +200,7 @@ class Renderer:
 
     def __init__(self, scene, width, height, max_iterations=15, seed=0x5EED, device=0, tile_rank=0, tile_world=1,
                  band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1,
-                 every_sphere_loop=False):
+                 every_sphere_loop=False, frame_lanes=0):
         L = device_lib()
         cfg = RenderConfig()
         _check(L.ptss_default_config(C.byref(cfg)))
@@ -212,6 +214,7 @@ class Renderer:
         cfg.timeKernels = 1 if time_kernels else 0
         cfg.samplesPerPass = samples_per_pass
         cfg.everySphereLoop = 1 if every_sphere_loop else 0
+        cfg.frameLanes = frame_lanes
         self.cfg = cfg
         self._scene = scene  # keep the arrays alive during create
         self._ctx = C.c_void_p()
@@ -330,6 +333,17 @@ class Renderer:
     def total_ray_bounces(self):
         v = C.c_ulonglong()
         _check(device_lib().ptss_total_ray_bounces(self._ctx, C.byref(v)))
+        return v.value
+
+    @property
+    def frame_lanes(self):
+        v = C.c_int()
+        _check(device_lib().ptss_frame_lanes(self._ctx, C.byref(v)))
+        return v.value
+
+    def guard_timeouts(self):
+        v = C.c_uint()
+        _check(device_lib().ptss_guard_timeouts(self._ctx, C.byref(v)))
         return v.value
 
     def bounce_kernel_time(self):

@@ -52,6 +52,11 @@ typedef struct ptss_render_config {
     /* Scenes with >= 64 finite spheres are traversed through spatially sorted sphere chunks (same image
      * as the reference's every-sphere loop, tests/test_gpu_many_spheres.py). 1 keeps the every-sphere loop for them too. */
     int everySphereLoop;
+    /* Frame lanes: the frame traced as K ray populations on K streams of the device, the tail of one lane's launches
+     * overlapping the other lanes' kernels. The image — loop guard included — does not depend on K.
+     * 0 = chosen from the size of a pass (2 for 2^20..2^24 rays per pass, e.g. 1920x1080 at one sample per tick; else 1),
+     * 1..4 = that many. */
+    int frameLanes;
 } ptss_render_config;
 
 /* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */
@@ -107,6 +112,12 @@ int ptss_live_counts(ptss_context* ctx, uint32_t* out, int cap, int* n);
 int ptss_total_ray_bounces(ptss_context* ctx, unsigned long long* out);
 /* HIP-event time of the bounce kernel since the last call (needs cfg.timeKernels): total ms, launches. */
 int ptss_bounce_kernel_time(ptss_context* ctx, double* total_ms, unsigned long long* launches);
+
+/* Frame lanes this context runs (cfg.frameLanes resolved). */
+int ptss_frame_lanes(const ptss_context* ctx, int* out);
+/* How often a lane gave up waiting for a peer lane's live count (a stream that never ran): always 0 in a healthy
+ * process; a non-zero value means the loop guard of that frame was decided without the peer. */
+int ptss_guard_timeouts(ptss_context* ctx, unsigned int* out);
 
 /* Diagnostic builds only (-DPTSS_STAMPS, tools/build_variants.py "stamps"): wave-cycles spent per kernel
  * phase, summed over all waves since creation; all zero in the shipped library. */

@@ -4,9 +4,9 @@
 Checks the contract line (one JSON line from rank 0, whole-job value, strong scaling), that sharding does not change
 the number of rays traced, and that the gathered frame IS the unsharded accumulator, element for element.
 
-The driver's own shape is 8 ranks; a GPU box admits at most 6 processes on its card at once, so the widest rehearsal here
-is 6 ranks (135 row bands over 6 ranks: uneven shards, so the gather's padding to the largest shard is exercised as it is
-at 8). RCCL itself cannot run here (one GPU): the collective path is covered over gloo only."""
+The driver's own shape is 8 ranks; a GPU box admits at most 6 processes on its card at once (the test runner itself
+is one of them), so the widest rehearsal here is 4 ranks (135 row bands over 4 ranks: uneven shards, so the gather's padding
+to the largest shard is exercised as it is at 8). RCCL itself cannot run here (one GPU): the collective path is covered over gloo only."""
 import json
 import os
 import subprocess
@@ -36,8 +36,8 @@ def run_bench(world, port, tmp_path, steps=2, warmup=1, extra=()):
 def test_ranks_print_one_contract_line_and_gather_the_unsharded_frame(tmp_path):
     one, frame1 = run_bench(1, 29541, tmp_path, extra=["--no-cpu-baseline"])
     two, frame2 = run_bench(2, 29542, tmp_path)
-    six, frame6 = run_bench(6, 29546, tmp_path)
-    for j, n in ((one, 1), (two, 2), (six, 6)):
+    six, frame6 = run_bench(4, 29546, tmp_path)
+    for j, n in ((one, 1), (two, 2), (six, 4)):
         assert j["n_gpus"] == n and j["steps"] == 2 and j["warmup"] == 1
         assert j["unit"] == "Mrays/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
         assert j["value"] > 0 and j["ms_per_step"] > 0

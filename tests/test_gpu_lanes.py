@@ -1,0 +1,102 @@
+"""Frame lanes (cfg.frameLanes; ptss_device.h "frame lanes"): one frame traced as K ray populations on K streams of the
+device. The image must not depend on K — including the reference's whole-frame loop guard `numRays > 128`
+(CudaTracer.cu:622), which a lane holding <= 128 rays decides by asking its peer lanes for their counts."""
+import numpy as np
+import pytest
+
+import oracle
+import ptss
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(preset, w, h, bounces, ticks, lanes, S=1, seed=0x5EED):
+    scene = ptss.Scene(preset)
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, seed=seed, float_accumulator=True, samples_per_pass=S, frame_lanes=lanes)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, seed=seed, samples_per_pass=S)
+    assert r.frame_lanes == lanes
+    for _ in range(ticks):
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts())
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert np.array_equal(r.float_accumulator(), o.float_sum(), equal_nan=True)
+    assert r.total_ray_bounces() == o.total_ray_bounces()
+    for p in (0, w * h // 2, w * h - 1):
+        assert np.array_equal(r.rng_state(p), o.rng_state(p))
+    assert r.guard_timeouts() == 0
+    r.close()
+    o.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+@pytest.mark.parametrize("preset,w,h,bounces,S", [("cornell", 64, 64, 5, 1), ("mixed", 100, 37, 8, 1), ("mixed", 48, 27, 6, 3)])
+def test_lanes_match_the_oracle(lanes, preset, w, h, bounces, S):
+    run_pair(preset, w, h, bounces, 3, lanes, S=S)
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("w,h,bounces", [(16, 8, 4), (8, 8, 3), (20, 10, 12), (24, 16, 15), (40, 20, 15)])
+def test_loop_guard_is_exact_across_lanes(lanes, w, h, bounces):
+    """Frames so small that the frame-wide live count falls to <= 128 at bounce 0 (128 and 64 pixels: nothing runs) or
+    somewhere along the path: every lane must stop exactly where the single population stops (the oracle's live counts
+    show where), so lanes that hold <= 128 rays have to add up their peers' counters."""
+    run_pair("cornell", w, h, bounces, 4, lanes)
+    run_pair("mixed", w, h, bounces, 2, lanes, S=2)
+
+
+def test_mode_and_bounce_count_changes_with_lanes():
+    """The two count buffers of a lane alternate per frame; a change of the bounce count between frames must not leave
+    stale counts behind (ray-tracing mode = 1 bounce, then back)."""
+    scene = ptss.Scene("mixed")
+    w, h = 72, 40
+    r = ptss.Renderer(scene, w, h, max_iterations=8, frame_lanes=2)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=8)
+    for step in range(9):
+        if step == 2:
+            r.set_mode(False); o.set_mode(False)
+        if step == 4:
+            r.set_mode(True); o.set_mode(True)
+        if step == 6:
+            r.set_max_iterations(3); o.set_max_iterations(3)
+        if step == 7:
+            r.set_max_iterations(11); o.set_max_iterations(11)
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts()), step
+        assert np.array_equal(r.accumulator(), o.accumulator()), step
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert r.guard_timeouts() == 0
+    r.close()
+
+
+def test_full_size_one_sample_per_tick_lanes_equal_one_population():
+    """1920x1080, one sample per tick (the reference's mode): the automatic choice is two lanes; 1, 2 and 4 lanes give the
+    same accumulator, display and counters."""
+    scene = ptss.Scene("mixed")
+    w, h, bounces = 1920, 1080, 8
+    out = {}
+    for lanes in (1, 0, 4):
+        r = ptss.Renderer(scene, w, h, max_iterations=bounces, sync_each_frame=False, frame_lanes=lanes)
+        if lanes == 0:
+            assert r.frame_lanes == 2
+        for _ in range(3):
+            r.generate_frame()
+        out[lanes] = (r.accumulator(), r.pixels(), r.live_counts().copy(), r.total_ray_bounces())
+        assert r.guard_timeouts() == 0
+        r.close()
+    for lanes in (0, 4):
+        assert np.array_equal(out[1][2], out[lanes][2]) and out[1][3] == out[lanes][3]
+        assert np.array_equal(out[1][0], out[lanes][0])
+        assert np.array_equal(out[1][1], out[lanes][1])
+
+
+def test_automatic_lane_count():
+    scene = ptss.Scene("cornell")
+    small = ptss.Renderer(scene, 64, 64)
+    assert small.frame_lanes == 1                      # 4,096 rays per pass: one launch round, nothing to overlap
+    small.close()
+    wide = ptss.Renderer(scene, 1920, 1080, samples_per_pass=40)
+    assert wide.frame_lanes == 1                       # 83 million rays per pass: launches are wide enough
+    wide.close()

@@ -11,6 +11,7 @@ spec.loader.exec_module(b)
 
 VARIANTS = {
     "knobs": ["PTSS_TUNING_KNOBS=1"],   # reads PTSS_GRID_CAP / PTSS_SCENE_PATH from the environment (tools/sweep_env.sh)
+    "lfork": ["PTSS_LANE_ALWAYS_FORK=1"],
     "cr1": ["PTSS_CLASS_RANK=1"],   # survivors ranked by material class inside the wave
     "cr2": ["PTSS_CLASS_RANK=2"],   # ... by direction octant
     "f7": ["PTSS_MINWAVES_FIRST=7"],   # bounce 0 at 6 waves per SIMD (80 VGPRs)
@@ -59,6 +60,7 @@ VARIANTS = {
     "a64": ["PTSS_ABLATE=64"],    # finishPath without the accumulator atomics (S > 1)
     "a128": ["PTSS_ABLATE=128"],  # finishPath without parking the RNG state
     "a15": ["PTSS_ABLATE=15"],
+    "a16": ["PTSS_ABLATE=16"],   # at most two sphere candidates per lane resolved (closest hit, dense any-hit)
     "g2": ["PTSS_TRI_GUARD2=1"],
     "r1": ["PTSS_SPHERE_UNROLL=0", "PTSS_TRI_STRAIGHT=0"],   # the round-1 loops
     "ts2": ["PTSS_TRI_STRAIGHT=2"],                      # one exit kept, bare reciprocal, min3, selects
