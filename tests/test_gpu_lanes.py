@@ -100,3 +100,50 @@ def test_automatic_lane_count():
     wide = ptss.Renderer(scene, 1920, 1080, samples_per_pass=40)
     assert wide.frame_lanes == 1                       # 83 million rays per pass: launches are wide enough
     wide.close()
+
+
+def test_lanes_inside_pixel_band_shards():
+    """Frame lanes and the multi-GPU pixel-band sharding compose: three shard contexts with two lanes each reassemble to
+    the oracle's frame (at a size where the sharded loop guard never differs)."""
+    import tiles
+    w, h, bounces, world, band = 96, 54, 6, 3, 4
+    scene = ptss.Scene("mixed")
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces)
+    rs = [ptss.Renderer(scene, w, h, max_iterations=bounces, tile_rank=k, tile_world=world, band_rows=band, frame_lanes=2,
+                        float_accumulator=True) for k in range(world)]
+    for _ in range(3):
+        o.generate_frame()
+        for r in rs:
+            r.generate_frame()
+    assert np.array_equal(tiles.untile([r.accumulator() for r in rs], w, h, band), o.accumulator())
+    assert np.array_equal(tiles.untile([r.pixels() for r in rs], w, h, band), o.pixels())
+    assert np.array_equal(tiles.untile([r.float_accumulator() for r in rs], w, h, band), o.float_sum(), equal_nan=True)
+    assert sum(r.total_ray_bounces() for r in rs) == o.total_ray_bounces()
+    for r in rs:
+        assert r.guard_timeouts() == 0
+        r.close()
+
+
+def test_lanes_with_callers_stream_and_buffers():
+    """The caller's stream is the join point: after generate_frame + a synchronize of THAT stream alone the caller-owned
+    accumulator and display buffer hold the frame, although the lanes ran on streams of their own."""
+    import torch
+    scene = ptss.Scene("cornell")
+    w = h = 96
+    r = ptss.Renderer(scene, w, h, max_iterations=5, sync_each_frame=False, frame_lanes=2)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=5)
+    acc = torch.zeros((w * h, 3), dtype=torch.int32, device="cuda")
+    pix = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    r.bind_accumulator(acc.data_ptr())
+    s = torch.cuda.Stream()
+    r.set_stream(s.cuda_stream)
+    for _ in range(4):
+        r.generate_frame(pix.data_ptr())
+        o.generate_frame()
+    s.synchronize()                                   # the caller's stream only
+    with torch.cuda.stream(s):
+        a, p = acc.cpu().numpy(), pix.cpu().numpy()
+    assert np.array_equal(a.astype(np.uint32), o.accumulator())
+    assert np.array_equal(p, o.pixels())
+    r.close()
