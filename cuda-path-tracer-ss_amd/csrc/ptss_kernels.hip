@@ -447,8 +447,20 @@ __device__ __forceinline__ uint32_t lowBitsClamped(int cnt) { return (cnt <= 0) 
 // fails the discriminant test never changes `distance`, so visiting only the candidates, in the
 // same order, accepts exactly what the reference's full loop accepts — but the square-root path
 // runs a few times per lane instead of once per sphere for the whole wave.
-#ifdef PTSS_CHIST
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
 __device__ unsigned long long g_chist[8];
+#endif
+// diagnostic build only (-DPTSS_SHIST, tools/scatter_hist.py): how many waves execute each block of scatter(), and for how many lanes
+#ifdef PTSS_SHIST
+#define PTSS_SCOUNT(k, cond)                                                                   \
+    do {                                                                                       \
+        const unsigned long long _m = __ballot(cond);                                          \
+        if (_m != 0ull && __lane_id() == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) { \
+            atomicAdd(&g_chist[k], 1ull + ((unsigned long long)__popcll(_m) << 32));           \
+        }                                                                                      \
+    } while (0)
+#else
+#define PTSS_SCOUNT(k, cond) do {} while (0)
 #endif
 struct Hit {
     float distance;
@@ -1085,6 +1097,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
     const int flags = (int)asU(mMisc.z);
 
     float r = ptrng::uniform(ray.rng);
+    PTSS_SCOUNT(0, true);  // waves (and lanes) in scatter at all
 
     int kind = kLobeNone;
     bool decided = false;
@@ -1102,6 +1115,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         }
     }
 
+    PTSS_SCOUNT(1, !decided);  // the non-Lambert block
     if (!decided) {
         // computeSinT2AndRefractiveIndexes :474-494 (flips cosI when inside)
         float n1, n2;
@@ -1121,6 +1135,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         const bool readsFresnel = (mSpecular.w > 0.0f && !(flags & PTSS_MAT_FLAG_PURE_REFLECTION)) || refrAvg > 0.0f;
         float n = 0.0f, sinT2 = 0.0f;
         float fresnelReflective = 1.0f;
+        PTSS_SCOUNT(2, readsFresnel);  // Snell / Fresnel terms
         if (readsFresnel) {
             n = ptm::div(n1, n2);
             sinT2 = n * n * (1.0f - cosI * cosI);
@@ -1166,6 +1181,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         if (!decided && refrAvg > 0.0f) {
             const float fresnelRefractive = 1.0f - fresnelReflective;
             r -= refrAvg * fresnelRefractive;
+            PTSS_SCOUNT(3, r < 0.0f);  // refraction lobe
             if (r < 0.0f) {
                 // refrRay :516-531
                 decided = true;
@@ -1181,6 +1197,10 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         if (!decided) ray.active = false;  // absorbed, :316-317
     }
 
+    PTSS_SCOUNT(4, kind != kLobeNone);       // the shared sampler tail
+    PTSS_SCOUNT(5, kind == kLobeBeckmann);   // ... with the Beckmann elevation (atan, log) and the Cook-Torrance weight
+    PTSS_SCOUNT(6, kind == kLobePhong);      // ... with the Phong elevation (pow)
+    PTSS_SCOUNT(7, kind == kLobeLambert);
     if (kind != kLobeNone) {  // one copy of the sampler for every kind
         const float u1 = ptrng::uniform(ray.rng);
         const float u2 = ptrng::uniform(ray.rng);
@@ -1914,7 +1934,7 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
     return hipGetLastError();
 }
 
-#ifdef PTSS_CHIST
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
 hipError_t readCandidateHist(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chist), 64); }
 #endif
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {

@@ -43,6 +43,7 @@ VARIANTS = {
     "ck8": ["PTSS_CHUNK=8"],
     "ck32": ["PTSS_CHUNK=32"],
     "chist": ["PTSS_CHIST=1"],
+    "shist": ["PTSS_SHIST=1"],   # scatter(): waves and lanes per block (tools/scatter_hist.py)
     "nosplit": ["PTSS_SPLIT_SPARSE=0"],
     "powq": ["PTSS_QUANT_TABLE=0"],  # literal clamp/pow/scale tone map
     "blockc": ["PTSS_WAVE_COMPACT=0"],
