@@ -147,3 +147,26 @@ def test_lanes_with_callers_stream_and_buffers():
     assert np.array_equal(a.astype(np.uint32), o.accumulator())
     assert np.array_equal(p, o.pixels())
     r.close()
+
+
+def test_lanes_free_running_for_many_frames():
+    """Lanes are forked from the caller's stream only at a reset and may drift up to a frame apart: 600 ticks without a
+    synchronisation in between (and a camera move in the middle = a reset and a fork) must end on the one-lane image."""
+    scene = ptss.Scene("mixed")
+    w, h, bounces = 640, 360, 8
+    out = {}
+    for lanes in (1, 2, 3):
+        r = ptss.Renderer(scene, w, h, max_iterations=bounces, sync_each_frame=False, frame_lanes=lanes)
+        cam = ptss.default_camera()
+        for t in range(600):
+            if t == 250:
+                cam.position.x = 0.125
+                r.set_camera(cam)
+            r.generate_frame()
+        out[lanes] = (r.accumulator(), r.pixels(), r.total_ray_bounces(), r.live_counts().copy())
+        assert r.guard_timeouts() == 0
+        r.close()
+    for lanes in (2, 3):
+        assert out[1][2] == out[lanes][2] and np.array_equal(out[1][3], out[lanes][3])
+        assert np.array_equal(out[1][0], out[lanes][0])
+        assert np.array_equal(out[1][1], out[lanes][1])

@@ -1,6 +1,6 @@
 """Per-rank frame time of the N-way pixel-tile shard, measured on ONE GPU by rendering rank 0's tile only
 (the ranks are independent until the final gather, so this is what each GPU of an N-GPU run does).
-   python tools/scale_emulate.py [steps]"""
+   python tools/scale_emulate.py [steps] [S] [frame_lanes: 0 = the library's choice]"""
 import os
 import sys
 import time
@@ -11,11 +11,12 @@ import ptss  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+LANES = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 scene = ptss.Scene("mixed")
 base = None
 for world in (1, 2, 4, 8):
     r = ptss.Renderer(scene, 1920, 1080, max_iterations=8, tile_rank=0, tile_world=world, band_rows=8, sync_each_frame=False,
-                      samples_per_pass=S)
+                      samples_per_pass=S, frame_lanes=LANES)
     for _ in range(30):
         r.generate_frame()
     r.synchronize()
@@ -28,6 +29,6 @@ for world in (1, 2, 4, 8):
     rays = r.total_ray_bounces() - r0
     ms = dt / steps * 1e3
     base = base or ms
-    print("S=%d " % S + "world %d: %.4f ms/step per rank, %7.1f Mrays/s per rank -> predicted aggregate %8.1f Mrays/s, speedup %.2fx, efficiency %.0f %%"
+    print("S=%d lanes=%d " % (S, r.frame_lanes) + "world %d: %.4f ms/step per rank, %7.1f Mrays/s per rank -> predicted aggregate %8.1f Mrays/s, speedup %.2fx, efficiency %.0f %%"
           % (world, ms, rays / dt / 1e6, rays / dt / 1e6 * world, base / ms, 100 * base / ms / world))
     r.close()
