@@ -237,6 +237,9 @@ def main():
         np.save(args.dump_frame, acc.cpu().numpy())
     rays = r.total_ray_bounces() - rays0
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
+    lanes = r.frame_lanes
+    if lanes > 1:   # the lanes' kernels overlap in time: a sum of their durations is not a launch time (a small shard of a
+        kms, klaunches = 0.0, 0   # multi-GPU frame gets two lanes); the roofline object is reported for one-lane runs only
     stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         mx = stats.clone()
@@ -265,6 +268,7 @@ def main():
                                    f"{spp_run} spp = {steps} passes x {samples} sample lanes per pixel",
                        "name": args.config,
                        "samples_per_pass": samples,
+                       "frame_lanes": lanes,
                        "sharding": f"{world} rank(s), interleaved {BAND_ROWS}-row pixel bands"
                                    + (", one RCCL gather of the uint3 accumulator" if world > 1 else ""),
                        "seed": SEED},
