@@ -59,3 +59,26 @@ def test_config5_runs_sharded(tmp_path):
     assert four["config"]["name"] == "c5" and four["n_gpus"] == 4
     assert four["ray_bounces"] == one["ray_bounces"]
     assert np.array_equal(f1.astype(np.int64), f4.astype(np.int64))
+
+
+def test_config2_line_is_complete(tmp_path):
+    """`bench.py --config c2` as the driver would run it on one GPU (short): the contract keys, the roofline object with its
+    HBM figures and — from the committed PMC summary of exactly this configuration — traffic and the VALU object, the S = 1
+    legs and the CPU baseline with its sample description."""
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["config"]["name"] == "c2" and "1280x720" in j["config"]["workload"] and "96 spp" in j["metric"]
+    roof = j["roofline"]
+    assert roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and roof["bound"] in ("hbm", "valu")
+    assert roof["traffic"] > 0 and "pmc_counters.json" in roof["traffic_source"]
+    assert 0 < roof["valu"]["issue_frac"] < 1 and 0 < roof["valu"]["lanes_active"] <= 1
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1 and "1280x720" in j["cpu_baseline"]["sample"]
+    assert j["s1_mrays_per_s"] > 0 and j["s1_one_lane_mrays_per_s"] > 0
