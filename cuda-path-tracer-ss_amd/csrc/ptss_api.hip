@@ -58,7 +58,8 @@ struct Lane {
     uint32_t* dCounts[2] = {nullptr, nullptr};   // alternate per frame (flushKernel arms the other one)
     uint32_t* dShardCount0 = nullptr;
     uint32_t* dLastCounts = nullptr;         // counts of the frame before (flushKernel's copy)
-    uint32_t* dDone = nullptr;               // [kMaxBounces + 1] words: "my counts of bounce b are final" = the frame's tag
+    uint32_t* dDone = nullptr;               // done[countIndex(b, s)]: workgroups of shard s that ended a bounce-b kernel, all frames (never reset)
+    uint32_t doneTarget[ptss::kMaxBounces + 1] = {};  // what done[b][*] add up to once everything launched so far has ended
                                              // (stored by this lane's bounce-b kernel as it starts: bounce b - 1 has then finished)
     hipEvent_t evDone[2] = {nullptr, nullptr};   // end of this lane's frame, by frame parity (several lanes only)
     uint32_t regionCap = 0;                  // slots per shard region of this lane's pools
@@ -83,7 +84,6 @@ struct ptss_context {
     bool haveAccel = false, accelActive = false;
     std::vector<Lane> lanes;
     hipEvent_t evFork = nullptr;            // several lanes: the caller's stream has reached this frame
-    uint32_t frameTag = 0;
     int countParity = 0;                    // which of a lane's two count buffers the next frame uses
     uint32_t* dRngHome = nullptr;
     unsigned long long* dTotal = nullptr;   // [0 .. kMaxLanes) ray-bounce totals per lane, [kMaxLanes .. +8) diagnostic phase stamps,
@@ -366,7 +366,6 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4*
     fb.laneCount = (uint32_t)c->lanes.size();
     fb.frameRays = c->numPixels * c->samples;
     fb.numPeers = fb.laneCount - 1;
-    fb.frameTag = c->frameTag;
     fb.myDone = ln.dDone;
     uint32_t p = 0;
     for (size_t k = 0; k < c->lanes.size(); ++k) {
@@ -571,8 +570,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
             CREATE_TRY(hipMemcpy(ln.dCounts[0] + ptss::countIndex(0, s), &shardCount0[k][s], sizeof(uint32_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&ln.dShardCount0, sizeof(shardCount0[k])));
         CREATE_TRY(hipMemcpy(ln.dShardCount0, shardCount0[k], sizeof(shardCount0[k]), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc(&ln.dDone, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
-        CREATE_TRY(hipMemset(ln.dDone, 0, (ptss::kMaxBounces + 1) * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&ln.dDone, ptss::kCountWords * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(ln.dDone, 0, ptss::kCountWords * sizeof(uint32_t)));
         if (numLanes > 1) {
             CREATE_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&ln.evDone[0], hipEventDisableTiming));
@@ -711,7 +710,6 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     }
     const int sample = ticks - c->lastResetTick;
     const int K = (int)c->lanes.size();
-    c->frameTag += 1;
     ptss::FrameBuffers fbs[ptss::kMaxLanes];
     for (int k = 0; k < K; ++k) fbs[k] = frameBuffers(c, k, pixels, sample);
 
@@ -791,15 +789,17 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
                 }
                 HIP_TRY(hipEventRecord(ev.a, ls));
             }
+            // the peers' done totals once their bounce i - 1 of this frame has ended (all of those launches precede this
+            // one in host order, so a kernel that waits for them never waits for something behind it in a shared queue)
+            if (i > 0)
+                for (int j = 0, p = 0; j < K; ++j)
+                    if (j != k) fbs[k].peerTarget[p++] = c->lanes[(size_t)j].doneTarget[i - 1];
             HIP_TRY(ptss::launchBounce(ls, fbs[k], c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks, c->tile, eye));
+            ln.doneTarget[i] += (uint32_t)blocks;  // every workgroup of the launch adds 1 to done[i][its shard] as it ends
             if (c->cfg.timeKernels) {
                 HIP_TRY(hipEventRecord(ev.b, ls));
                 c->evBusy.push_back(ev);
             }
-            // Lanes 1..: "my counts of bounce i + 1 are final", behind the kernel that made them — for the lanes whose
-            // bounce i + 1 is enqueued before this lane's (they may share its hardware queue and cannot wait for this
-            // lane's own bounce-(i + 1) kernel to start; lane 0 is first in every round and is waited for that way only).
-            if (k > 0 && i + 1 < numIterations) HIP_TRY(ptss::launchSignal(ls, ln.dDone + (i + 1), c->frameTag));
         }
     }
     for (int k = 0; k < K; ++k) {
@@ -810,7 +810,13 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         if (K > 1 && c->frameIndex > 0)
             for (int j = 0; j < K; ++j)
                 if (j != k) HIP_TRY(hipStreamWaitEvent(ls, c->lanes[(size_t)j].evDone[(c->frameIndex - 1) & 1u], 0));
-        HIP_TRY(ptss::launchFlush(ls, fbs[k], numIterations));  // :637
+        ptss::FlushTargets targets{};
+        for (int j = 0, p = 0; j < K; ++j)
+            if (j != k) {
+                for (int b = 0; b <= ptss::kMaxBounces; ++b) targets.target[p][b] = c->lanes[(size_t)j].doneTarget[b];
+                ++p;
+            }
+        HIP_TRY(ptss::launchFlush(ls, fbs[k], numIterations, targets));  // :637
         // every 8th frame (and until a hint exists) copy counts[] to pinned memory for later grid sizing
         if (!ln.haveHint || (c->frameIndex & 7u) == 0) {
             const int q = (int)((c->frameIndex >> 3) & 3u);

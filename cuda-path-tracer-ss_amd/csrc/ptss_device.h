@@ -172,13 +172,15 @@ struct EyeParams {  // computeEyeRay constants evaluated once on the host with p
 // accumulator, display) is shared — lanes touch disjoint pixels. The tail of one lane's launch overlaps the other lanes'
 // kernels. The loop guard `numRays > 128` (CudaTracer.cu:622) stays a WHOLE-FRAME quantity: a lane whose own count is
 // above 128 knows the frame's is; only a lane holding <= 128 rays (then at most one workgroup per shard has work) waits
-// for its peers' counts of that bounce and adds them up. A lane publishes "my counts of bounce b are final" itself: the
-// first thing its bounce-b kernel does is store the frame's tag into done[b] — the stream is in order, so bounce b - 1 has
-// finished when bounce b starts. That serves the peers whose own bounce-b kernel was enqueued later; a peer enqueued
-// EARLIER may share a hardware queue with this lane and must not wait for a kernel behind it, so lanes 1.. also publish
-// the word from a one-thread kernel enqueued right behind bounce b - 1 (in host order before any lane's bounce b). (A
-// stream-ordered hipStreamWriteValue32 after every kernel of every lane cost 9 %, a one-thread kernel after each 4 %; lane
-// 0 needs none.) So the image is the one-lane image, exactly, for every K, whatever the streams' queue mapping.
+// for its peers' counts of that bounce and adds them up. "Peer p's counts of bounce b are final" means: every workgroup of
+// p's bounce b - 1 launch has ended. Each workgroup of a bounce kernel therefore adds 1 to its lane's done[b - 1][shard]
+// as its last act (sixteen counters per bounce, one per 128-B line, never reset: they grow by the grid size of every
+// frame's launch), and the host hands each launch the total the peers' counters reach once their bounce b - 1 of THIS
+// frame is through (it knows every grid it launched). The waiter only ever depends on kernels that were enqueued before
+// it — all lanes' bounce b - 1 launches precede any lane's bounce b in host order — so lanes that share a hardware queue
+// cannot deadlock. (Earlier designs, measured: a stream-ordered hipStreamWriteValue32 after every kernel cost 9 %; a done
+// word stored at the START of bounce b plus a one-thread signal kernel behind bounce b - 1 of lanes 1.. cost 4 %.)
+// So the image is the one-lane image, exactly, for every K, whatever the streams' queue mapping.
 constexpr int kMaxLanes = 4;
 
 struct FrameBuffers {
@@ -209,10 +211,11 @@ struct FrameBuffers {
     uint32_t laneIndex, laneCount;
     uint32_t frameRays;              // rays all lanes together start a pass with (numPixels x samples): bounce 0's guard
     uint32_t numPeers;               // laneCount - 1
-    uint32_t frameTag;               // value the peers' `done` words carry for the current frame
-    const uint32_t* peerCounts[kMaxLanes - 1];        // the peers' counts[] of the current frame
-    const volatile uint32_t* peerDone[kMaxLanes - 1]; // peerDone[p][b] == frameTag: peer p's counts[b] are final
-    uint32_t* myDone;                // this lane's own words
+    const uint32_t* peerCounts[kMaxLanes - 1];  // the peers' counts[] of the current frame
+    const uint32_t* peerDone[kMaxLanes - 1];    // the peers' done[countIndex(b, s)]: workgroups of shard s that ended bounce b, all frames
+    uint32_t peerTarget[kMaxLanes - 1];         // bounce kernel of bounce b: what peer p's done[b - 1][*] add up to once its bounce
+                                                // b - 1 of this frame has ended (compared wrap-safe)
+    uint32_t* myDone;                // this lane's own counters
     uint32_t* guardTimeouts;         // incremented if a peer's word never arrived (must stay 0; ptss_generate_frame reports it)
 };
 
@@ -225,8 +228,10 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
                         bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
-hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces);  // one per lane
-hipError_t launchSignal(hipStream_t st, uint32_t* word, uint32_t value);
+struct FlushTargets {  // flushKernel re-derives the guard of every bounce: target[p][b] = peer p's done total after ITS bounce b of this frame
+    uint32_t target[kMaxLanes - 1][kMaxBounces + 1];
+};
+hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces, const FlushTargets& targets);  // one per lane
 int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool accel);
 
 }  // namespace ptss

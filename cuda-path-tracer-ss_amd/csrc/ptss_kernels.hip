@@ -1325,19 +1325,24 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 #define PTSS_STAMP_FLUSH() do {} while (0)
 #endif
 
-// ---- the loop guard with frame lanes (FrameBuffers, "frame lanes"): the frame's live count of bounce b when this lane's
-// own count `own` is not above the threshold. Waits (bounded) for each peer's "counts of bounce b are final" word, then
-// adds the peers' sixteen shard counters. Called by at most one workgroup per shard of a lane that holds <= 128 rays.
-__device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int bounce, uint32_t own) {
+// ---- the loop guard with frame lanes (FrameBuffers, "frame lanes"): the frame's live count of bounce b >= 1 when this
+// lane's own count `own` is not above the threshold. Waits (bounded) until every workgroup of each peer's bounce b - 1 has
+// ended (the peer's done counters reach `target[p]`), then adds the peer's sixteen shard counters of bounce b.
+// Called by at most one workgroup per shard of a lane that holds <= 128 rays, and by flushKernel.
+__device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int bounce, uint32_t own, const uint32_t* target) {
     uint32_t total = own;
     for (uint32_t p = 0; p < fb.numPeers; ++p) {
         uint32_t spins = 0;
-        // (>=, wrap-safe: lanes may run up to one frame apart, and the peer stores a newer tag over this frame's; its counts
-        // of THIS frame stay intact meanwhile — they live in the buffer its flushKernel re-arms only after this lane's frame)
-        while ((int32_t)(__hip_atomic_load(const_cast<const uint32_t*>(fb.peerDone[p]) + bounce, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
-                         fb.frameTag) < 0) {
+        for (;;) {
+            uint32_t ended = 0;
+            for (int s = 0; s < kShards; ++s)
+                ended += __hip_atomic_load(fb.peerDone[p] + countIndex(bounce - 1, s), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            // (>=, wrap-safe: lanes may run up to one frame apart, and a peer that is ahead has added its next frame's
+            // workgroups already; its counts of THIS frame stay intact meanwhile — they live in the buffer its flushKernel
+            // re-arms only after this lane's frame)
+            if ((int32_t)(ended - target[p]) >= 0) break;
             __builtin_amdgcn_s_sleep(64);
-            if (++spins > (1u << 22)) {  // ~ seconds: a peer stream that never runs; do not hang the device
+            if (++spins > (1u << 20)) {  // ~ seconds: a peer stream that never runs; do not hang the device
                 if (threadIdx.x == 0) atomicAdd(fb.guardTimeouts, 1u);
                 break;
             }
@@ -1459,18 +1464,10 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
 // that scenes without it run exactly the code they ran before.
 template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
-__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : PTSS_MINWAVES)) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
-   FrameBuffers fb, const float4* __restrict__ sceneBlob,
-                                                                      SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
+__device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
+                                           const TileMap& tile, const EyeParams& eye) {
     extern __shared__ float4 lds[];
     const uint32_t shard = blockIdx.x % kShards;
-    // frame lanes: this kernel runs, so this lane's bounce - 1 has finished — its counts of `bounce` are final; tell the
-    // peers BEFORE deciding anything (two lanes that both hold <= 128 rays wait for each other's word below). Peers whose
-    // kernel of this bounce was enqueued AFTER this one rely on this store; the others get the word from a signalKernel
-    // behind this lane's previous bounce (ptss_generate_frame) — a waiting kernel must never depend on a kernel that may
-    // sit behind it in a shared hardware queue.
-    if (fb.numPeers != 0 && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(fb.myDone + bounce, fb.frameTag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
     if constexpr (kFirst) {
         if (fb.frameRays <= fb.minLive) return;  // loop guard, CudaTracer.cu:622: the frame starts with <= 128 rays
@@ -1479,7 +1476,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
         if (n <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
             uint32_t own = 0;   // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
             for (int s = 0; s < kShards; ++s) own += fb.counts[countIndex(bounce, s)];
-            if (own <= fb.minLive && frameLiveCount(fb, bounce, own) <= fb.minLive) return;
+            if (own <= fb.minLive && frameLiveCount(fb, bounce, own, fb.peerTarget) <= fb.minLive) return;
         }
     }
 
@@ -1829,9 +1826,24 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
     }
 }
 
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
+__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : PTSS_MINWAVES)) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
+    FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
+    bounceBody<kLast, kSceneInLds, kFirst, kAccel>(fb, sceneBlob, L, bounce, tile, eye);
+    // frame lanes: "this workgroup of bounce `bounce` has ended" (every workgroup, also one that had nothing to do) — the
+    // peers' loop guard of bounce + 1 waits for the whole grid (frameLiveCount). The survivor counters were raised by
+    // returning device-scope atomics, so they have been performed when a wave gets here, and the barrier collects the
+    // workgroup's waves: a relaxed add is enough. (A RELEASE here writes the XCD's L2 back once per workgroup: 3x slower.)
+    if (fb.numPeers != 0) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add(fb.myDone + countIndex(bounce, (int)(blockIdx.x % kShards)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // After the last launched bounce: tone-map whatever the loop guard left alive (<= 128 rays in all
 // shards together), and add this frame's ray-bounce total to the running counter.
-__global__ void flushKernel(FrameBuffers fb, int numBounces) {
+__global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets targets) {
     __shared__ uint32_t totals[kMaxBounces + 1];
     __shared__ int stopShared;
     for (int b = threadIdx.x; b <= numBounces; b += blockDim.x) {
@@ -1845,7 +1857,15 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces) {
         unsigned long long sum = 0;
         for (int b = 0; b < numBounces; ++b) {
             uint32_t frame = totals[b];
-            if (frame <= fb.minLive) frame = (b == 0) ? fb.frameRays : frameLiveCount(fb, b, frame);
+            if (frame <= fb.minLive) {
+                if (b == 0) {
+                    frame = fb.frameRays;
+                } else {
+                    uint32_t want[kMaxLanes - 1];
+                    for (int p = 0; p < kMaxLanes - 1; ++p) want[p] = targets.target[p][b - 1];
+                    frame = frameLiveCount(fb, b, frame, want);
+                }
+            }
             if (frame <= fb.minLive) {
                 stop = b;
                 break;
@@ -1958,15 +1978,8 @@ hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sc
 #undef PTSS_GO
 }
 
-// "this lane's counts of bounce b are final", published behind the kernel that made them (see ptss_generate_frame for who needs it)
-__global__ void signalKernel(uint32_t* word, uint32_t value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-hipError_t launchSignal(hipStream_t st, uint32_t* word, uint32_t value) {
-    hipLaunchKernelGGL(signalKernel, dim3(1), dim3(1), 0, st, word, value);
-    return hipGetLastError();
-}
-
-hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces) {
-    hipLaunchKernelGGL(flushKernel, dim3(1), dim3(kMinLiveRays), 0, st, fb, numBounces);
+hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces, const FlushTargets& targets) {
+    hipLaunchKernelGGL(flushKernel, dim3(1), dim3(kMinLiveRays), 0, st, fb, numBounces, targets);
     return hipGetLastError();
 }
 
