@@ -1,4 +1,5 @@
-"""tools/lanes_bench.py [config=c3] [S=1] [passes=200] — whole-frame Mrays/s of one context with 1, 2, 3, 4 frame lanes."""
+"""tools/lanes_bench.py [config=c3] [S=1] [passes=200] [width height] — whole-frame Mrays/s of one context with 1, 2, 3, 4 frame
+lanes (width/height override the config's frame: where does the automatic choice belong?)."""
 import os
 import sys
 import time
@@ -10,7 +11,9 @@ import torch  # noqa: E402
 import ptss  # noqa: E402
 from bench import CONFIGS  # noqa: E402
 
-cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+cfg = dict(CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"])
+if len(sys.argv) > 5:
+    cfg["width"], cfg["height"] = int(sys.argv[4]), int(sys.argv[5])
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 scene = ptss.Scene(cfg["preset"])
@@ -29,6 +32,6 @@ for lanes in (1, 2, 3, 4, 1, 2):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rays = r.total_ray_bounces() - r0
-    print("%s S=%d lanes=%d: %.4f ms per pass, %.1f Mrays/s, guard timeouts %d" % (sys.argv[1] if len(sys.argv) > 1 else "c3", S, lanes,
+    print("%s %dx%d S=%d lanes=%d: %.4f ms per pass, %.1f Mrays/s, guard timeouts %d" % (sys.argv[1] if len(sys.argv) > 1 else "c3", cfg["width"], cfg["height"], S, lanes,
           dt / passes * 1e3, rays / dt / 1e6, r.guard_timeouts()))
     r.close()
