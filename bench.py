@@ -149,6 +149,9 @@ def main():
     # (collectives staged through host memory) in place of RCCL.
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    # ... and the N > 1 code path (process group, barrier, gather, all-reduce) taken with ONE rank: the only way RCCL itself
+    # — its communicator, its kernels, next to libptss.so's HIP runtime in one process — can be executed on a one-GPU box.
+    ap.add_argument("--collectives-at-one-rank", action="store_true")
     ap.add_argument("--dump-frame", default=None, help="tests: rank 0 saves the whole-frame integer accumulator (.npy)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -175,9 +178,13 @@ def main():
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     dist = None
-    if world > 1:
+    if world > 1 or args.collectives_at_one_rank:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --collectives-at-one-rank without a launcher
+            os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -195,7 +202,7 @@ def main():
     pix = torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda")
     r.bind_accumulator(acc.data_ptr())
     gather_list = None
-    if world > 1:
+    if dist is not None:
         sizes = [len(ptss.tile_rows(H, BAND_ROWS, k, world)) * W for k in range(world)]
         maxn = max(sizes)
         send = torch.zeros((maxn, 3), dtype=torch.int32, device=coll_dev)

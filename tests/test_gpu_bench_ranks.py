@@ -6,7 +6,8 @@ the number of rays traced, and that the gathered frame IS the unsharded accumula
 
 The driver's own shape is 8 ranks; a GPU box admits at most 6 processes on its card at once (the test runner itself
 is one of them), so the widest rehearsal here is 4 ranks (135 row bands over 4 ranks: uneven shards, so the gather's padding
-to the largest shard is exercised as it is at 8). RCCL itself cannot run here (one GPU): the collective path is covered over gloo only."""
+to the largest shard is exercised as it is at 8). RCCL refuses two ranks on one device, so the sharded runs talk over gloo;
+RCCL itself is executed with ONE rank through the same code path (test_rccl_itself_runs_the_collective_path_with_one_rank)."""
 import json
 import os
 import subprocess
@@ -19,13 +20,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(world, port, tmp_path, steps=2, warmup=1, extra=()):
-    dump = os.path.join(str(tmp_path), f"frame_{world}.npy")
+def run_bench(world, port, tmp_path, steps=2, warmup=1, extra=(), rehearsal=("--rehearse-on-one-gpu", "--backend", "gloo")):
+    dump = os.path.join(str(tmp_path), f"frame_{world}_{port}.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup),
-           "--rehearse-on-one-gpu", "--backend", "gloo", "--no-s1-leg", "--dump-frame", dump] + list(extra)
+           "--no-s1-leg", "--dump-frame", dump] + list(rehearsal) + list(extra)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -50,6 +51,18 @@ def test_ranks_print_one_contract_line_and_gather_the_unsharded_frame(tmp_path):
     assert frame1.shape == frame2.shape == frame6.shape == (1920 * 1080, 3)
     assert np.array_equal(frame1.astype(np.int64), frame2.astype(np.int64))
     assert np.array_equal(frame1.astype(np.int64), frame6.astype(np.int64))
+
+
+def test_rccl_itself_runs_the_collective_path_with_one_rank(tmp_path):
+    """What a one-GPU box can execute of the real thing: bench.py's N > 1 code path — init_process_group("nccl"), barriers,
+    the gather of the int32 accumulator tile, the all-reduces of the timing record — with world size 1 over RCCL, in the
+    process that also holds libptss.so and its HIP runtime. The line and the frame are those of the plain one-GPU run."""
+    plain, frame_plain = run_bench(1, 29561, tmp_path, extra=["--no-cpu-baseline"], rehearsal=())
+    rccl, frame_rccl = run_bench(1, 29562, tmp_path, extra=["--no-cpu-baseline", "--collectives-at-one-rank", "--backend", "nccl"],
+                                 rehearsal=())
+    assert rccl["n_gpus"] == 1 and rccl["ray_bounces"] == plain["ray_bounces"]
+    assert frame_rccl.shape == (1920 * 1080, 3)
+    assert np.array_equal(frame_plain.astype(np.int64), frame_rccl.astype(np.int64))
 
 
 def test_config5_runs_sharded(tmp_path):
