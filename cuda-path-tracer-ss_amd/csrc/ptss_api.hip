@@ -136,7 +136,7 @@ namespace {
 // i.e. the centre's ray parameter p = -d^.vC satisfies -p > R + m (|vC| + R). Every member then has p_i + r_i < -m |v_i|,
 // so both roots the reference computes, L p_i +- sqrt(L^2 p_i^2 - |v_i|^2 + r_i^2) with L^2 = |d|^2 in 1 +- 1e-5, are
 // below -0.0018 |p_i| — negative beyond any float32 error — and Sphere::intersectRay returns false (Primitives.h:137).
-// Requires finite, moderate geometry (|coordinate|, radius <= 1e15) so that no discriminant overflows; packScene and
+// Requires finite, moderate geometry (|coordinate|, radius <= 1e15, radius >= 1e-12) so that no discriminant overflows; packScene and
 // the per-frame camera check fall back to the plain image otherwise.
 constexpr double kAccelM = 5e-3;
 constexpr float kAccelLimit = 1e15f;
@@ -148,6 +148,7 @@ bool accelEligible(const ptss_scene_desc& s) {
     for (size_t i = 0; i < s.numSpheres; ++i) {
         const ptss_sphere& sp = s.spheres[i];
         if (!ok(sp.position.x) || !ok(sp.position.y) || !ok(sp.position.z) || !ok(sp.radius)) return false;
+        if (!(std::fabs(sp.radius) >= 1e-12f)) return false;  // shiftInSphereBounded (ptss_kernels.hip): r^2 well inside the normal range
     }
     for (size_t i = 0; i < s.numTriangles; ++i) {
         const ptss_triangle& t = s.triangles[i];

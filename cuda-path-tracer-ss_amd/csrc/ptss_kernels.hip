@@ -379,6 +379,21 @@ __device__ __forceinline__ void shiftInSpherePrimary(uint32_t& rev, float4 pv, v
     const float b = dot(d, xyz(pv)) * 2;
     shiftInMayHit(rev, b * b, 4 * pv.w);
 }
+// The same verdict from two instructions less, for the chunked traversal only (accelEligible, ptss_api.hip: every
+// |coordinate| and radius in [1e-12, 1e15], camera in range, so ray origins — the camera or points on primitives — are
+// bounded as well): with h = d.v the reference compares RN((2h)^2) with 4c; doubling and quadrupling are exact, so that
+// is 4 RN(h^2) < 4c, i.e. RN(h^2) < c, unless (a) 4c overflows — c < 2^105 here —, (b) 4 h^2 overflows — then h^2 >= 2^126 > c
+// and both forms say "may hit" —, or (c) h^2 is subnormal and loses bits that 4 h^2 keeps — then h^2 < 2^-126, while c is
+// zero or at least an ulp of r^2 >= 1e-24 in magnitude (a difference of two floats), so its sign decides both forms
+// alike (c = 0: neither `<` holds). NaN or infinite operands make both compares false. Pinned on adversarial operands
+// by tests/test_sphere_forms.py. (In the 38-primitive kernels the shorter form LOSES 3 %: the allocator answers with
+// 32 instead of 16 bytes of scratch at their 72-register budget; the chunked kernels run at 5 waves and gain 1.7 %.)
+__device__ __forceinline__ void shiftInSphereBounded(uint32_t& rev, float4 sp, vec3 o, vec3 d) {
+    const vec3 v = o - xyz(sp);
+    const float h = dot(d, v);
+    const float c = dot(v, v) - sp.w;
+    shiftInMayHit(rev, h * h, c);
+}
 template <bool kPrimary>
 __device__ __forceinline__ uint32_t sphereCandidates(const float4* rows, int cnt, vec3 o, vec3 d) {
     const int trips = (cnt + 3) >> 2;  // wave-uniform, 1..8
@@ -512,12 +527,12 @@ __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec
 
 // Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
 // from position (chunk mod kChunkSpheres) on, wrapping, so that the 16-byte gathers of a wave spread over the LDS banks;
-// verdicts enter through the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
+// verdicts enter through the carry (shiftInSphereBounded), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
 // of that mask back into the sphere's slot inside the chunk. The traversal is order-free (ties go by original index).
 __device__ __forceinline__ uint32_t chunkCandidates(const float4* spheres /* sc + L.offSphere */, int base, int chunk, vec3 o, vec3 d) {
     uint32_t rev = 0;
 #pragma unroll 4
-    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
+    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphereBounded(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
     return rev;
 }
 __device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSpheres - 1 - bit) + chunk) & (kChunkSpheres - 1); }
