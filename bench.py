@@ -110,7 +110,7 @@ def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes
     for k in range(shards):
         r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
                           tile_rank=k, tile_world=shards, band_rows=BAND_ROWS, sync_each_frame=False, samples_per_pass=1,
-                          frame_lanes=frame_lanes)
+                          frame_lanes=frame_lanes if shards == 1 else 1)   # shard contexts: one lane each (the experiment is the two contexts)
         r.set_stream(torch.cuda.Stream().cuda_stream if shards > 1 else torch.cuda.current_stream().cuda_stream)
         rs.append(r)
         pix.append(torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda"))
