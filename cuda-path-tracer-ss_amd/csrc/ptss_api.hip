@@ -142,13 +142,15 @@ constexpr double kAccelM = 5e-3;
 constexpr float kAccelLimit = 1e15f;
 constexpr int kAccelMinSpheres = 64;
 
-bool accelEligible(const ptss_scene_desc& s) {
-    if (s.numSpheres < (size_t)kAccelMinSpheres) return false;
-    auto ok = [](float v) { return std::fabs(v) <= kAccelLimit; };  // false for NaN and infinities as well
+// Finite, moderate geometry: every |coordinate| <= 1e15, every sphere radius in [1e-12, 1e15] (false for NaN and infinities).
+// What the chunked traversal requires, and what lets the sphere candidate tests take their shorter form
+// (SceneLayout::sphereBounded, ptss_kernels.hip shiftInSphere<true>: r^2 well inside the normal range, no discriminant near overflow).
+bool geometryBounded(const ptss_scene_desc& s) {
+    auto ok = [](float v) { return std::fabs(v) <= kAccelLimit; };
     for (size_t i = 0; i < s.numSpheres; ++i) {
         const ptss_sphere& sp = s.spheres[i];
         if (!ok(sp.position.x) || !ok(sp.position.y) || !ok(sp.position.z) || !ok(sp.radius)) return false;
-        if (!(std::fabs(sp.radius) >= 1e-12f)) return false;  // shiftInSphereBounded (ptss_kernels.hip): r^2 well inside the normal range
+        if (!(std::fabs(sp.radius) >= 1e-12f)) return false;
     }
     for (size_t i = 0; i < s.numTriangles; ++i) {
         const ptss_triangle& t = s.triangles[i];
@@ -159,6 +161,12 @@ bool accelEligible(const ptss_scene_desc& s) {
         if (!ok(s.pointLights[i].position.x) || !ok(s.pointLights[i].position.y) || !ok(s.pointLights[i].position.z)) return false;
     return true;
 }
+bool cameraInRange(const ptss_camera& cam) {
+    auto ok = [](float v) { return std::fabs(v) <= kAccelLimit; };
+    return ok(cam.position.x) && ok(cam.position.y) && ok(cam.position.z);
+}
+
+bool accelEligible(const ptss_scene_desc& s) { return s.numSpheres >= (size_t)kAccelMinSpheres && geometryBounded(s); }
 
 // sorted position -> original index. The spheres are split recursively at the median of their centres along the axis of
 // largest extent (a kd-tree built by std::nth_element; ties by original index, so the order is deterministic), the cut
@@ -240,6 +248,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         if (!finite3(s.pointLights[i].power)) L.neeSkipSafe = 0;
     for (size_t i = 0; i < s.numAreaLights; ++i)
         if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
+    L.sphereBounded = geometryBounded(s) ? 1 : 0;  // see SceneLayout::sphereBounded
     L.triDetBounded = 1;  // see SceneLayout::triDetBounded
     for (size_t i = 0; i < s.numTriangles; ++i) {
         const ptss_triangle& t = s.triangles[i];
@@ -503,10 +512,11 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         const unsigned long long rays = (unsigned long long)c->numPixels * c->samples;
         // measured (tools/lanes_bench.py, Mrays/s with 1 / 2 / 3 / 4 lanes): 1920x1080 S = 1 (2.1 M rays per pass) 13,500 /
         // 15,000-15,900 / 14,700 / 9,800; 3840x2160 1,024 spheres S = 1 (8.3 M) 4,000 / 4,250 / 4,410 / 3,310; 1280x720 S = 1
-        // (0.9 M) 9,280-9,360 / 9,590-10,250 / 9,450 / 5,150; 800x600 (0.48 M) 7,270-7,330 / 7,230-7,690; 512x512 (0.26 M) 4,600-4,650 /
-        // 4,030-4,450: below ~0.2 ms a pass is ten launch latencies, nothing to overlap; 1920x1080 S = 40 (83 M) 17,000 /
-        // 17,150 / 16,970 / 16,620. Four lanes (five streams with the caller's) share hardware queues and serialise.
-        if (numLanes == 0) numLanes = (rays >= (3ull << 18) && rays <= (1ull << 24)) ? 2 : 1;
+        // (0.9 M) 9,280-9,360 / 9,590-10,250 / 9,450 / 5,150 in one run, 9,390 / 8,470-9,430 in others — no consistent gain; 800x600
+        // (0.48 M) 7,270-7,330 / 7,230-7,690; 512x512 (0.26 M) 4,600-4,650 / 4,030-4,450: below ~0.3 ms a pass is ten launch
+        // latencies, nothing to overlap; 1920x1080 S = 40 (83 M) 17,000 / 17,150 / 16,970 / 16,620. Four lanes (five streams with
+        // the caller's) share hardware queues and serialise.
+        if (numLanes == 0) numLanes = (rays >= (1ull << 20) && rays <= (1ull << 24)) ? 2 : 1;
     }
     c->lanes.resize((size_t)numLanes);
     uint32_t shardCount0[ptss::kMaxLanes][ptss::kShards] = {{0}};
@@ -693,8 +703,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     }
 
     if (c->haveAccel) {  // the chunked image assumes a camera within the geometry's magnitude range (packScene)
-        auto inRange = [](float v) { return std::fabs(v) <= kAccelLimit; };
-        const bool want = inRange(c->camera.position.x) && inRange(c->camera.position.y) && inRange(c->camera.position.z);
+        const bool want = cameraInRange(c->camera);
         if (want != c->accelActive) {
             std::swap(c->dScene, c->dSceneAlt);
             std::swap(c->layout, c->layoutAlt);
@@ -761,6 +770,8 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         for (Lane& ln : c->lanes) HIP_TRY(hipStreamWaitEvent(ln.stream, c->evFork, 0));
     }
     if (c->cfg.timeKernels) drainKernelEvents(c, false);
+    // the shorter sphere candidate test: bounded geometry AND a camera within the same range (ray origins are the camera or points on primitives)
+    const bool bounded = c->layout.sphereBounded != 0 && cameraInRange(c->camera);
     for (int i = 0; i < numIterations; ++i) {  // :622-633, guard evaluated on the device
         for (int k = 0; k < K; ++k) {
             Lane& ln = c->lanes[(size_t)k];
@@ -796,7 +807,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             if (i > 0)
                 for (int j = 0, p = 0; j < K; ++j)
                     if (j != k) fbs[k].peerTarget[p++] = c->lanes[(size_t)j].doneTarget[i - 1];
-            HIP_TRY(ptss::launchBounce(ls, fbs[k], c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, blocks, c->tile, eye));
+            HIP_TRY(ptss::launchBounce(ls, fbs[k], c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, bounded, blocks, c->tile, eye));
             ln.doneTarget[i] += (uint32_t)blocks;  // every workgroup of the launch adds 1 to done[i][its shard] as it ends
             if (c->cfg.timeKernels) {
                 HIP_TRY(hipEventRecord(ev.b, ls));

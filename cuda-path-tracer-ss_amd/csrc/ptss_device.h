@@ -40,6 +40,11 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
                           // PTSS_DEFER_LOADS the only scratch left is in a cold IEEE-division escape block. Measured, same box:
                           // 5 waves (96 VGPRs) 13.3, 6 (80) 14.2, 7 (72) 14.5, 8 (64, spills) 11.4 Grays/s
 #endif
+#ifndef PTSS_MINWAVES_BOUNDED
+#define PTSS_MINWAVES_BOUNDED 6   // the instantiations for bounded scenes (SceneLayout::sphereBounded: the shorter sphere test) want 80
+                                  // registers: at 7 waves the shorter test costs 3 % (32 instead of 16 B of scratch), at 6 it gains — same-box
+                                  // A/B against 7 waves + the long test: c3 +0.5 %, c2 +2.3 %, one sample per tick at 1080p +2.5-3 %
+#endif
 #ifndef PTSS_MINWAVES_FIRST
 #define PTSS_MINWAVES_FIRST 6   // bounce 0's instantiation (eye rays fused in, camera-origin tests) has its own register budget:
                                 // at 7 waves it spills 32 B (18 scratch accesses per tile), at 6 (80 VGPRs) none —
@@ -148,6 +153,8 @@ struct SceneLayout {
     int ldsVec4;        // rows [0, ldsVec4) are staged into LDS; the rest (the many-sphere integer tables: material, original
                         // index, position — read only when a hit is accepted) stay in global memory
     int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
+    int sphereBounded;  // 1: every |coordinate| <= 1e15 and every sphere radius in [1e-12, 1e15]: the sphere candidate tests may take
+                        //    the two-instructions-shorter discriminant form (ptss_kernels.hip shiftInSphere<true>) while the camera is in range
     int triDetBounded;  // 1: every triangle has |e1| |e2| <= 2^100 (finite), so |det| = |e1 . (d x e2)| < 2^126 whenever
                         //    |d|^2 < 2^30 — the closest-hit triangle loop may then use the reciprocal's fast path unguarded
 };
@@ -226,7 +233,7 @@ hipError_t launchDisplay(hipStream_t st, const FrameBuffers& fb);
 hipError_t launchClear(hipStream_t st, const FrameBuffers& fb);
 hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayout& layout, ptss_vec3 origin);
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye);
+                        bool isLast, bool sceneInLds, bool bounded, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
 struct FlushTargets {  // flushKernel re-derives the guard of every bounce: target[p][b] = peer p's done total after ITS bounce b of this frame
     uint32_t target[kMaxLanes - 1][kMaxBounces + 1];

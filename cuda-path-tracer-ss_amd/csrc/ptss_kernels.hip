@@ -369,71 +369,79 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
 __device__ __forceinline__ void shiftInMayHit(uint32_t& rev, float bb, float c4) {
     asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rev) : "v"(bb), "v"(c4) : "vcc");
 }
+// kBounded: the same verdict from two instructions less, on bounded geometry (SceneLayout::sphereBounded, set by
+// ptss_create: every |coordinate| <= 1e15 and every sphere radius in [1e-12, 1e15]; the camera is checked per frame; ray
+// origins — the camera or points on primitives — are then bounded as well). With h = d.v the reference compares
+// RN((2h)^2) with 4c; doubling and quadrupling are exact, so that is 4 RN(h^2) < 4c, i.e. RN(h^2) < c, unless (a) 4c
+// overflows — c < 2^105 here —, (b) 4 h^2 overflows — then h^2 >= 2^126 > c and both forms say "may hit" —, or (c) h^2 is
+// subnormal and loses bits that 4 h^2 keeps — then h^2 < 2^-126, while c is zero or at least an ulp of r^2 >= 1e-24 in
+// magnitude (a difference of two floats), so its sign decides both forms alike (c = 0: neither `<` holds). NaN or
+// infinite operands make both compares false. Pinned on adversarial operands by tests/test_sphere_forms.py.
+template <bool kBounded>
 __device__ __forceinline__ void shiftInSphere(uint32_t& rev, float4 sp, vec3 o, vec3 d) {  // sphereMayHit's operations
     const vec3 v = o - xyz(sp);
-    const float b = dot(d, v) * 2;
-    const float c = dot(v, v) - sp.w;
-    shiftInMayHit(rev, b * b, 4 * c);
+    if constexpr (kBounded) {
+        const float h = dot(d, v);
+        const float c = dot(v, v) - sp.w;
+        shiftInMayHit(rev, h * h, c);
+    } else {
+        const float b = dot(d, v) * 2;
+        const float c = dot(v, v) - sp.w;
+        shiftInMayHit(rev, b * b, 4 * c);
+    }
 }
+template <bool kBounded>
 __device__ __forceinline__ void shiftInSpherePrimary(uint32_t& rev, float4 pv, vec3 d) {  // sphereMayHitPrimary's
-    const float b = dot(d, xyz(pv)) * 2;
-    shiftInMayHit(rev, b * b, 4 * pv.w);
+    if constexpr (kBounded) {
+        const float h = dot(d, xyz(pv));
+        shiftInMayHit(rev, h * h, pv.w);
+    } else {
+        const float b = dot(d, xyz(pv)) * 2;
+        shiftInMayHit(rev, b * b, 4 * pv.w);
+    }
 }
-// The same verdict from two instructions less, for the chunked traversal only (accelEligible, ptss_api.hip: every
-// |coordinate| and radius in [1e-12, 1e15], camera in range, so ray origins — the camera or points on primitives — are
-// bounded as well): with h = d.v the reference compares RN((2h)^2) with 4c; doubling and quadrupling are exact, so that
-// is 4 RN(h^2) < 4c, i.e. RN(h^2) < c, unless (a) 4c overflows — c < 2^105 here —, (b) 4 h^2 overflows — then h^2 >= 2^126 > c
-// and both forms say "may hit" —, or (c) h^2 is subnormal and loses bits that 4 h^2 keeps — then h^2 < 2^-126, while c is
-// zero or at least an ulp of r^2 >= 1e-24 in magnitude (a difference of two floats), so its sign decides both forms
-// alike (c = 0: neither `<` holds). NaN or infinite operands make both compares false. Pinned on adversarial operands
-// by tests/test_sphere_forms.py. (In the 38-primitive kernels the shorter form LOSES 3 %: the allocator answers with
-// 32 instead of 16 bytes of scratch at their 72-register budget; the chunked kernels run at 5 waves and gain 1.7 %.)
-__device__ __forceinline__ void shiftInSphereBounded(uint32_t& rev, float4 sp, vec3 o, vec3 d) {
-    const vec3 v = o - xyz(sp);
-    const float h = dot(d, v);
-    const float c = dot(v, v) - sp.w;
-    shiftInMayHit(rev, h * h, c);
-}
-template <bool kPrimary>
+template <bool kPrimary, bool kBounded>
 __device__ __forceinline__ uint32_t sphereCandidates(const float4* rows, int cnt, vec3 o, vec3 d) {
     const int trips = (cnt + 3) >> 2;  // wave-uniform, 1..8
     uint32_t rev = 0;
     for (int g = 0; g < trips; ++g) {
         const float4 r0 = rows[4 * g], r1 = rows[4 * g + 1], r2 = rows[4 * g + 2], r3 = rows[4 * g + 3];
         if constexpr (kPrimary) {
-            shiftInSpherePrimary(rev, r0, d);
-            shiftInSpherePrimary(rev, r1, d);
-            shiftInSpherePrimary(rev, r2, d);
-            shiftInSpherePrimary(rev, r3, d);
+            shiftInSpherePrimary<kBounded>(rev, r0, d);
+            shiftInSpherePrimary<kBounded>(rev, r1, d);
+            shiftInSpherePrimary<kBounded>(rev, r2, d);
+            shiftInSpherePrimary<kBounded>(rev, r3, d);
         } else {
-            shiftInSphere(rev, r0, o, d);
-            shiftInSphere(rev, r1, o, d);
-            shiftInSphere(rev, r2, o, d);
-            shiftInSphere(rev, r3, o, d);
+            shiftInSphere<kBounded>(rev, r0, o, d);
+            shiftInSphere<kBounded>(rev, r1, o, d);
+            shiftInSphere<kBounded>(rev, r2, o, d);
+            shiftInSphere<kBounded>(rev, r3, o, d);
         }
     }
     return __builtin_bitreverse32(rev) >> (32 - 4 * trips);
 }
 // two spheres per trip: for the shadow passes, where the registers are needed elsewhere (four rows in flight there
 // push the 72-VGPR kernel into scratch)
+template <bool kBounded>
 __device__ __forceinline__ uint32_t sphereCandidatesPairs(const float4* rows, int cnt, vec3 o, vec3 d) {
     const int trips = (cnt + 1) >> 1;  // 1..16
     uint32_t rev = 0;
     for (int g = 0; g < trips; ++g) {
         const float4 r0 = rows[2 * g], r1 = rows[2 * g + 1];
-        shiftInSphere(rev, r0, o, d);
-        shiftInSphere(rev, r1, o, d);
+        shiftInSphere<kBounded>(rev, r0, o, d);
+        shiftInSphere<kBounded>(rev, r1, o, d);
     }
     return __builtin_bitreverse32(rev) >> (32 - 2 * trips);
 }
+template <bool kBounded>
 __device__ __forceinline__ uint32_t sphereCandidatesStridedPairs(const float4* first, int stride, int cnt, vec3 o, vec3 d) {
     const int trips = (cnt + 1) >> 1;
     uint32_t rev = 0;
     for (int g = 0; g < trips; ++g) {
         const float4* p = first + 2 * g * stride;
         const float4 r0 = p[0], r1 = p[stride];
-        shiftInSphere(rev, r0, o, d);
-        shiftInSphere(rev, r1, o, d);
+        shiftInSphere<kBounded>(rev, r0, o, d);
+        shiftInSphere<kBounded>(rev, r1, o, d);
     }
     return __builtin_bitreverse32(rev) >> (32 - 2 * trips);
 }
@@ -441,16 +449,17 @@ __device__ __forceinline__ uint32_t lowBits(int cnt) { return (cnt >= 32) ? 0xff
 // the same for a lane that visits every `stride`-th sphere starting at its own `first` row (anyHitSplit). Rows past the
 // scene's last sphere may be read (at most 31 of them: other rows of the scene image, which always ends in the 65-row
 // tone-map table); their bits are dropped by the caller.
+template <bool kBounded>
 __device__ __forceinline__ uint32_t sphereCandidatesStrided(const float4* first, int stride, int cnt, vec3 o, vec3 d) {
     const int trips = (cnt + 3) >> 2;
     uint32_t rev = 0;
     for (int g = 0; g < trips; ++g) {
         const float4* p = first + 4 * g * stride;
         const float4 r0 = p[0], r1 = p[stride], r2 = p[2 * stride], r3 = p[3 * stride];
-        shiftInSphere(rev, r0, o, d);
-        shiftInSphere(rev, r1, o, d);
-        shiftInSphere(rev, r2, o, d);
-        shiftInSphere(rev, r3, o, d);
+        shiftInSphere<kBounded>(rev, r0, o, d);
+        shiftInSphere<kBounded>(rev, r1, o, d);
+        shiftInSphere<kBounded>(rev, r2, o, d);
+        shiftInSphere<kBounded>(rev, r3, o, d);
     }
     return __builtin_bitreverse32(rev) >> (32 - 4 * trips);
 }
@@ -527,12 +536,12 @@ __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec
 
 // Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
 // from position (chunk mod kChunkSpheres) on, wrapping, so that the 16-byte gathers of a wave spread over the LDS banks;
-// verdicts enter through the carry (shiftInSphereBounded), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
+// verdicts enter through the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
 // of that mask back into the sphere's slot inside the chunk. The traversal is order-free (ties go by original index).
 __device__ __forceinline__ uint32_t chunkCandidates(const float4* spheres /* sc + L.offSphere */, int base, int chunk, vec3 o, vec3 d) {
     uint32_t rev = 0;
 #pragma unroll 4
-    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphereBounded(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
+    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere<true>(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
     return rev;
 }
 __device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSpheres - 1 - bit) + chunk) & (kChunkSpheres - 1); }
@@ -865,7 +874,7 @@ __device__ __forceinline__ bool anyTriangles(const float4* sc, const SceneLayout
 }
 #endif
 
-template <bool kPrimary, bool kAccel>
+template <bool kPrimary, bool kAccel, bool kBounded>
 __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
     Hit h;
     h.distance = ptm::inf();
@@ -880,7 +889,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
 #if PTSS_SPHERE_UNROLL & 1
-        uint32_t mask = sphereCandidates<kPrimary>(sc + (kPrimary ? L.offPrimSphere : L.offSphere) + base, cnt, o, d);
+        uint32_t mask = sphereCandidates<kPrimary, kBounded>(sc + (kPrimary ? L.offPrimSphere : L.offSphere) + base, cnt, o, d);
         mask &= live ? lowBits(cnt) : 0u;
 #else
         uint32_t mask = 0;
@@ -967,7 +976,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
 // ---- the any-hit loops of lineOfSight, CudaTracer.cu:437-452: true when some primitive blocks the
 // segment. Order-independent (the reference returns at the first accepted primitive and no test
 // depends on another). `live`: this lane carries a segment. -----------------------------------------
-template <bool kAccel>
+template <bool kAccel, bool kBounded>
 __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance,
                                        bool live) {
     bool occluded = false;
@@ -975,10 +984,10 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
 #if PTSS_SPHERE_UNROLL & 8
-        uint32_t mask = sphereCandidatesPairs(sc + L.offSphere + base, cnt, lo, w_i);
+        uint32_t mask = sphereCandidatesPairs<kBounded>(sc + L.offSphere + base, cnt, lo, w_i);
         mask &= (live && !occluded) ? lowBits(cnt) : 0u;
 #elif PTSS_SPHERE_UNROLL & 2
-        uint32_t mask = sphereCandidates<false>(sc + L.offSphere + base, cnt, lo, w_i);
+        uint32_t mask = sphereCandidates<false, kBounded>(sc + L.offSphere + base, cnt, lo, w_i);
         mask &= (live && !occluded) ? lowBits(cnt) : 0u;
 #else
         uint32_t mask = 0;
@@ -1031,6 +1040,7 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
 // the scalar test on the same operands, and lineOfSight's answer is an OR over independent tests, so the verdict is
 // the one anyHit gives. Used when a pass over the wave's queue holds fewer than 64 segments: 8 segments x 8 lanes
 // cost an eighth of a dense pass instead of a whole one. Rows are gathered per lane here (no broadcast). ------------
+template <bool kBounded>
 __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance,
                                             bool live, int shift, int sub) {
     bool occluded = false;
@@ -1039,10 +1049,10 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
     for (int base = 0; base < sphereSteps; base += 32) {
         const int cnt = (sphereSteps - base < 32) ? (sphereSteps - base) : 32;
 #if PTSS_SPHERE_UNROLL & 16
-        uint32_t mask = sphereCandidatesStridedPairs(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
+        uint32_t mask = sphereCandidatesStridedPairs<kBounded>(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
         mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
 #elif PTSS_SPHERE_UNROLL & 4
-        uint32_t mask = sphereCandidatesStrided(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
+        uint32_t mask = sphereCandidatesStrided<kBounded>(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
         // this lane's spheres are sub, sub + g, ...: step j exists for it iff (j << shift) + sub < numSpheres
         mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
 #else
@@ -1478,7 +1488,7 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // eye ray in registers (no ray pool read) and intersects with the camera-origin precomputes.
 // kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
 // that scenes without it run exactly the code they ran before.
-template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded>
 __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
                                            const TileMap& tile, const EyeParams& eye) {
     extern __shared__ float4 lds[];
@@ -1571,7 +1581,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit<kFirst && !kAccel, kAccel>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
+        const Hit h = closestHit<kFirst && !kAccel, kAccel, kBounded>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
 #endif
         PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
@@ -1687,10 +1697,10 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                     occ = anySpheresHybrid(sc, L, wq + e0, wq + (e0 == 0u ? 64 : 0), lo, wi, reach, have);
                     occ = occ || anyTriangles(sc, L, lo, wi, reach, have && !occ);
                 } else {
-                    occ = (shift == 0) ? anyHit<kAccel>(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+                    occ = (shift == 0) ? anyHit<kAccel, kBounded>(sc, L, lo, wi, reach, have) : anyHitSplit<kBounded>(sc, L, lo, wi, reach, have, shift, (int)sub);
                 }
 #else
-                const bool occ = (shift == 0) ? anyHit<kAccel>(sc, L, lo, wi, reach, have) : anyHitSplit(sc, L, lo, wi, reach, have, shift, (int)sub);
+                const bool occ = (shift == 0) ? anyHit<kAccel, kBounded>(sc, L, lo, wi, reach, have) : anyHitSplit<kBounded>(sc, L, lo, wi, reach, have, shift, (int)sub);
 #endif
                 const unsigned long long verdicts = __ballot(occ);  // all lanes vote before anyone branches
                 const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
@@ -1707,7 +1717,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 const uint32_t es = have ? e : 0u;
                 const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
                 const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
-                const bool occ = anyHit<kAccel>(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
+                const bool occ = anyHit<kAccel, kBounded>(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
                 if (have && occ) {
                     const uint32_t ow = wqOwner[es];
                     wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1;
@@ -1841,10 +1851,10 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
     }
 }
 
-template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel>
-__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : PTSS_MINWAVES)) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded>
+__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES))) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
     FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
-    bounceBody<kLast, kSceneInLds, kFirst, kAccel>(fb, sceneBlob, L, bounce, tile, eye);
+    bounceBody<kLast, kSceneInLds, kFirst, kAccel, kBounded>(fb, sceneBlob, L, bounce, tile, eye);
     // frame lanes: "this workgroup of bounce `bounce` has ended" (every workgroup, also one that had nothing to do) — the
     // peers' loop guard of bounce + 1 waits for the whole grid (frameLiveCount). The survivor counters were raised by
     // returning device-scope atomics, so they have been performed when a wave gets here, and the barrier collects the
@@ -1960,11 +1970,11 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
     return hipGetLastError();
 }
 
-template <bool kLast, bool kLds, bool kFirst, bool kAccel>
+template <bool kLast, bool kLds, bool kFirst, bool kAccel, bool kBounded>
 static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout,
                                 int bounce, int gridBlocks, const TileMap& tile, const EyeParams& eye) {
     const size_t lds = bounceLdsBytes(layout, kLds);
-    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst, kAccel>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
+    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst, kAccel, kBounded>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
                        tile, eye);
     return hipGetLastError();
 }
@@ -1977,12 +1987,13 @@ size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
 }
 
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
-                        bool isLast, bool sceneInLds, int gridBlocks, TileMap tile, EyeParams eye) {
+                        bool isLast, bool sceneInLds, bool bounded, int gridBlocks, TileMap tile, EyeParams eye) {
     const bool isFirst = bounce == 0;
 #define PTSS_GO(a, b, c)                                                                                   \
     do {                                                                                                   \
-        if (layout.accelSpheres) return launchBounceT<a, b, c, true>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
-        return launchBounceT<a, b, c, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);   \
+        if (layout.accelSpheres) return launchBounceT<a, b, c, true, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
+        if (bounded) return launchBounceT<a, b, c, false, true>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);           \
+        return launchBounceT<a, b, c, false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);                       \
     } while (0)
     if (sceneInLds) {
         if (isFirst) { if (isLast) PTSS_GO(true, true, true); else PTSS_GO(false, true, true); }
@@ -2004,11 +2015,14 @@ int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool 
     int a = 0;
     hipError_t e;
     if (accel)
-        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, true>, kBlock, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, true>, kBlock, lds);
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, true, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, true, false>, kBlock, lds);
+    else if (layout.sphereBounded)
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, true>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, true>, kBlock, lds);
     else
-        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false>, kBlock, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false>, kBlock, lds);
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, false>, kBlock, lds);
     return e == hipSuccess ? a : 0;
 }
 

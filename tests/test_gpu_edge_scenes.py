@@ -139,6 +139,34 @@ def test_overflowing_geometry_follows_the_same_inf_nan_path():
     check(build(spheres=sph, triangles=FLOOR + LAMP, area=[((50, 50, 50), 2)]), 32, 20, 4, nan_ok=True)
 
 
+def test_sphere_test_forms_switch_with_the_geometry_and_the_camera():
+    """Scenes of finite, moderate geometry run the sphere candidate tests in their shorter form (SceneLayout::sphereBounded,
+    tests/test_sphere_forms.py) as long as the camera is in range as well; a radius below 1e-12 or a coordinate beyond 1e15
+    keeps the reference's literal form, and a camera that leaves the range switches instantiation for that frame. All of
+    them against the oracle, bit for bit."""
+    base = [((0, 0, -3), 0.8, COOK), ((-1.6, -0.2, -4), 0.7, GLASS), ((1.5, 0.1, -3.5), 0.6, MIRROR)]
+    lit = dict(triangles=FLOOR + LAMP, area=[((50, 50, 50), 2)])
+    check(build(spheres=base, **lit), 40, 24, 5)                                        # bounded
+    check(build(spheres=base + [((0.5, -0.5, -2), 1e-13, RED)], **lit), 40, 24, 5)      # a radius under the bound
+    check(build(spheres=base + [((0, 3e15, -3), 1.0, RED)], **lit), 40, 24, 5)          # a coordinate over the bound
+    # the camera leaves the range and comes back: same context, three instantiations of the same frame loop
+    scene = build(spheres=base, **lit)
+    r = ptss.Renderer(scene, 40, 24, max_iterations=5, float_accumulator=True)
+    o = oracle.Oracle(scene.desc, 40, 24, max_iterations=5)
+    cam = ptss.default_camera()
+    for z in (0.0, 4e15, 0.5):
+        cam.position.z = z
+        r.set_camera(cam)
+        o.set_camera(cam)
+        for _ in range(2):
+            r.generate_frame()
+            o.generate_frame()
+            assert np.array_equal(r.live_counts(), o.live_counts()), z
+        assert np.array_equal(r.accumulator(), o.accumulator()), z
+        assert np.array_equal(r.float_accumulator(), o.float_sum(), equal_nan=True), z
+    r.close()
+
+
 @pytest.mark.parametrize("bounces", [1, 64])
 def test_bounce_count_limits_in_a_mirror_box(bounces):
     box = (quad((-2, -2, 1), (2, -2, 1), (2, -2, -6), (-2, -2, -6), MIRROR) + quad((-2, 2, 1), (-2, 2, -6), (2, 2, -6), (2, 2, 1), MIRROR) +
