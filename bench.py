@@ -128,6 +128,8 @@ def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes
     for _ in range(passes):
         frame()
     torch.cuda.synchronize()
+    for r in rs:
+        r.synchronize()
     dt = time.perf_counter() - t0
     rays = sum(r.total_ray_bounces() for r in rs) - r0
     for r in rs:

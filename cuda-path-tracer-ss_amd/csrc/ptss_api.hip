@@ -377,11 +377,15 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4*
     fb.frameRays = c->numPixels * c->samples;
     fb.numPeers = fb.laneCount - 1;
     fb.myDone = ln.dDone;
+    fb.myFrameDone = ln.dDone + ptss::kCountWords;
+    fb.frameSeq = c->frameIndex;
+    fb.joinsFrame = (laneIdx + 1 == (int)c->lanes.size()) ? 1u : 0u;
     uint32_t p = 0;
     for (size_t k = 0; k < c->lanes.size(); ++k) {
         if ((int)k == laneIdx) continue;
         fb.peerCounts[p] = c->lanes[k].dCounts[c->countParity];
         fb.peerDone[p] = c->lanes[k].dDone;
+        fb.peerFrameDone[p] = c->lanes[k].dDone + ptss::kCountWords;
         ++p;
     }
     return fb;
@@ -582,8 +586,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
             CREATE_TRY(hipMemcpy(ln.dCounts[0] + ptss::countIndex(0, s), &shardCount0[k][s], sizeof(uint32_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&ln.dShardCount0, sizeof(shardCount0[k])));
         CREATE_TRY(hipMemcpy(ln.dShardCount0, shardCount0[k], sizeof(shardCount0[k]), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc(&ln.dDone, ptss::kCountWords * sizeof(uint32_t)));
-        CREATE_TRY(hipMemset(ln.dDone, 0, ptss::kCountWords * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&ln.dDone, (ptss::kCountWords + ptss::kCountStride) * sizeof(uint32_t)));  // + the finished-frames counter
+        CREATE_TRY(hipMemset(ln.dDone, 0, (ptss::kCountWords + ptss::kCountStride) * sizeof(uint32_t)));
         if (numLanes > 1) {
             CREATE_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&ln.evDone[0], hipEventDisableTiming));
@@ -818,11 +822,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     for (int k = 0; k < K; ++k) {
         Lane& ln = c->lanes[(size_t)k];
         hipStream_t ls = K > 1 ? ln.stream : st;
-        // flushKernel re-arms the count buffer of the frame BEFORE this one for the frame after it; a peer lane may still
-        // be reading that buffer (it can run one frame behind), so the flush waits for every peer's previous frame
-        if (K > 1 && c->frameIndex > 0)
-            for (int j = 0; j < K; ++j)
-                if (j != k) HIP_TRY(hipStreamWaitEvent(ls, c->lanes[(size_t)j].evDone[(c->frameIndex - 1) & 1u], 0));
+        // (flushKernel itself waits, on the device, until every peer lane has finished the previous frame: FrameBuffers::myFrameDone)
         ptss::FlushTargets targets{};
         for (int j = 0, p = 0; j < K; ++j)
             if (j != k) {
@@ -840,7 +840,9 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
                 ln.hintPending[q] = true;
             }
         }
-        if (K > 1) {  // the join: the caller's stream is ordered behind every lane's frame (the lanes themselves run on)
+        // the join: the caller's stream is ordered behind every lane's frame (the lanes themselves run on) — ONE event, behind
+        // the last lane's flushKernel, which ends only when every other lane's has (FrameBuffers::joinsFrame); an event per lane cost 1-2 %
+        if (K > 1 && k == K - 1) {
             HIP_TRY(hipEventRecord(ln.evDone[c->frameIndex & 1u], ls));
             HIP_TRY(hipStreamWaitEvent(st, ln.evDone[c->frameIndex & 1u], 0));
         }

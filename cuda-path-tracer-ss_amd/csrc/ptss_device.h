@@ -223,6 +223,15 @@ struct FrameBuffers {
     uint32_t peerTarget[kMaxLanes - 1];         // bounce kernel of bounce b: what peer p's done[b - 1][*] add up to once its bounce
                                                 // b - 1 of this frame has ended (compared wrap-safe)
     uint32_t* myDone;                // this lane's own counters
+    // flushKernel re-arms the count buffer of the frame BEFORE this one for the frame after it, and a peer lane may run one
+    // frame behind and still read that buffer: each lane counts its finished frames (flushKernel's last act), and a flush
+    // waits (bounded) until every peer has finished the previous frame. (As stream-ordered event waits between the lanes'
+    // streams the same dependency cost 3.5 % of a 1080p pass at one sample per tick.)
+    uint32_t* myFrameDone;                          // frames this lane has finished, all time
+    const uint32_t* peerFrameDone[kMaxLanes - 1];
+    uint32_t frameSeq;                              // frames finished before this one (what the peers' counters must have reached)
+    uint32_t joinsFrame;                            // 1 in the LAST lane: its flushKernel also waits for the peers' flushes of THIS frame (all of them
+                                                    // enqueued before it), so that one event behind it orders the caller's stream after the whole frame
     uint32_t* guardTimeouts;         // incremented if a peer's word never arrived (must stay 0; ptss_generate_frame reports it)
 };
 

@@ -1933,6 +1933,19 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
     }
     // keep this frame's counters for the host (live counts, grid hints) and arm the OTHER buffer for the next frame:
     // bounce 0 = the shard's pixels, every later bounce 0. This frame's buffer stays as it is: a peer lane may still read it.
+    // The other buffer is the one of the frame before this: a peer that runs a frame behind may still be reading it, so
+    // wait until every peer has finished that frame (its flushKernel was enqueued before this one: no deadlock in a shared queue).
+    if (threadIdx.x == 0)
+        for (uint32_t p = 0; p < fb.numPeers; ++p) {
+            uint32_t spins = 0;
+            while ((int32_t)(__hip_atomic_load(fb.peerFrameDone[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fb.frameSeq) < 0) {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > (1u << 20)) {
+                    atomicAdd(fb.guardTimeouts, 1u);
+                    break;
+                }
+            }
+        }
     __syncthreads();
     // (every bounce slot, not just this frame's: the other buffer still holds the counts of two frames ago, and the
     // bounce count may change between frames — ptss_set_mode, ptss_set_max_iterations)
@@ -1940,6 +1953,24 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
         const int b = k / kShards, s = k % kShards;
         fb.lastCounts[countIndex(b, s)] = (b <= numBounces) ? fb.counts[countIndex(b, s)] : 0u;
         fb.countsNext[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
+    }
+    // this lane has finished the frame: every read of a peer's counters (thread 0, above) has returned by now
+    if (fb.numPeers != 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (fb.joinsFrame)   // the last lane's flush ends only when the whole frame has (the join event sits behind it)
+                for (uint32_t p = 0; p < fb.numPeers; ++p) {
+                    uint32_t spins = 0;
+                    while ((int32_t)(__hip_atomic_load(fb.peerFrameDone[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fb.frameSeq + 1u)) < 0) {
+                        __builtin_amdgcn_s_sleep(64);
+                        if (++spins > (1u << 20)) {
+                            atomicAdd(fb.guardTimeouts, 1u);
+                            break;
+                        }
+                    }
+                }
+            __hip_atomic_store(fb.myFrameDone, fb.frameSeq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
