@@ -1429,7 +1429,19 @@ __global__ void displayKernel(FrameBuffers fb) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= fb.numPixels) return;
     U3 t = reinterpret_cast<const U3*>(fb.accum)[p];
-    for (uint32_t l = 0; l < fb.samples; ++l) {  // this pass's S samples of the pixel (finishPath), coalesced per lane plane
+    uint32_t l = 0;
+    for (; l + 8 <= fb.samples; l += 8) {  // this pass's S samples of the pixel (finishPath), coalesced per lane plane; eight
+        uint32_t q[8];                      // independent fetches in flight per thread (one at a time ran at 2.6 TB/s)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = fb.staged[(l + k) * fb.plane + p];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t.x += q[k] & 255u;
+            t.y += (q[k] >> 8) & 255u;
+            t.z += (q[k] >> 16) & 255u;
+        }
+    }
+    for (; l < fb.samples; ++l) {
         const uint32_t q = fb.staged[l * fb.plane + p];
         t.x += q & 255u;
         t.y += (q >> 8) & 255u;
