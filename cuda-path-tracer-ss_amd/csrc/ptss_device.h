@@ -44,6 +44,7 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_MINWAVES_BOUNDED 6   // the instantiations for bounded scenes (SceneLayout::sphereBounded: the shorter sphere test) want 80
                                   // registers: at 7 waves the shorter test costs 3 % (32 instead of 16 B of scratch), at 6 it gains — same-box
                                   // A/B against 7 waves + the long test: c3 +0.5 %, c2 +2.3 %, one sample per tick at 1080p +2.5-3 %
+                                  // (5 waves, 96 registers: -3.5 %; with four spheres per trip in the shadow passes as well: -4.5 %)
 #endif
 #ifndef PTSS_MINWAVES_FIRST
 #define PTSS_MINWAVES_FIRST 6   // bounce 0's instantiation (eye rays fused in, camera-origin tests) has its own register budget:

@@ -12,6 +12,10 @@ spec.loader.exec_module(b)
 VARIANTS = {
     "knobs": ["PTSS_TUNING_KNOBS=1"],   # reads PTSS_GRID_CAP / PTSS_SCENE_PATH from the environment (tools/sweep_env.sh)
     "lfork": ["PTSS_LANE_ALWAYS_FORK=1"],
+    "wb5": ["PTSS_MINWAVES_BOUNDED=5"],   # the bounded-geometry instantiations at 5 / 7 waves per SIMD
+    "wb7": ["PTSS_MINWAVES_BOUNDED=7"],
+    "wb5su7": ["PTSS_MINWAVES_BOUNDED=5", "PTSS_SPHERE_UNROLL=7"],
+    "wb6su7": ["PTSS_SPHERE_UNROLL=7"],
     "cr1": ["PTSS_CLASS_RANK=1"],   # survivors ranked by material class inside the wave
     "cr2": ["PTSS_CLASS_RANK=2"],   # ... by direction octant
     "f7": ["PTSS_MINWAVES_FIRST=7"],   # bounce 0 at 6 waves per SIMD (80 VGPRs)
