@@ -167,6 +167,19 @@ def test_sphere_test_forms_switch_with_the_geometry_and_the_camera():
     r.close()
 
 
+def test_walls_made_of_giant_spheres():
+    """The smallpt way of building a room: walls are spheres of radius 1e5. Leaving such a wall, c = |v|^2 - r^2 is ~2 r bump =
+    20 against b^2 ~ 4e10 — below half an ulp of b^2, so the discriminant rounds to b^2, one root comes out as exactly 0 and
+    the reference's `t0 < 0 && t1 < 0` exit does not fire (Primitives.h:137): whatever the literal arithmetic does there,
+    both sphere-test forms (geometry is bounded: the shorter one runs) must do the same, bit for bit."""
+    R = 1e5
+    sph = [((-R - 3, 0, -5), R, RED), ((R + 3, 0, -5), R, GREEN), ((0, 0, -R - 9), R, CREAM), ((0, -R - 2, -5), R, CREAM),
+           ((0, R + 3, -5), R, CREAM), ((-1.2, -1.2, -6), 0.8, MIRROR), ((1.1, -1.3, -4.5), 0.7, GLASS), ((0, -0.5, -5.5), 0.4, COOK)]
+    counts = check(build(spheres=sph, point=[((0, 2.5, -5), (60, 60, 60))]), 56, 40, 8, ticks=3)
+    assert counts[3] > 0
+    check(build(spheres=sph, point=[((0, 2.5, -5), (60, 60, 60))]), 40, 24, 6, ticks=2, S=3)
+
+
 @pytest.mark.parametrize("bounces", [1, 64])
 def test_bounce_count_limits_in_a_mirror_box(bounces):
     box = (quad((-2, -2, 1), (2, -2, 1), (2, -2, -6), (-2, -2, -6), MIRROR) + quad((-2, 2, 1), (-2, 2, -6), (2, 2, -6), (2, 2, 1), MIRROR) +
