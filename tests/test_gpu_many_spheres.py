@@ -61,6 +61,22 @@ def test_large_random_scenes(seed, ns, nt):
     run_pair(scene, int(rng.integers(48, 100)), int(rng.integers(27, 60)), int(rng.integers(3, 9)), S=int(rng.choice([1, 3])), seed=seed)
 
 
+def test_giant_wall_spheres_among_many_small_ones():
+    """A smallpt-style room (walls = spheres of radius 1e5: chunk bounds a hundred thousand units wide, discriminants that
+    cancel to b^2) filled with 90 small spheres: the chunked traversal and its shorter sphere test against the oracle."""
+    R = 1e5
+    rng = np.random.default_rng(11)
+    mats = [RED, GREEN, CREAM, MIRROR, COOK, PHONG, GLASS]
+    spheres = [((-R - 3, 0, -5), R, RED), ((R + 3, 0, -5), R, GREEN), ((0, 0, -R - 9), R, CREAM), ((0, -R - 2, -5), R, CREAM),
+               ((0, R + 3, -5), R, CREAM)]
+    for _ in range(90):
+        spheres.append(((float(rng.uniform(-2.6, 2.6)), float(rng.uniform(-1.8, 2.6)), float(rng.uniform(-8.5, -2.5))),
+                        float(rng.uniform(0.08, 0.3)), mats[int(rng.integers(0, len(mats)))]))
+    scene = build(spheres=spheres, point=[((0, 2.7, -5), (70, 70, 70)), ((1.5, 0, -1.5), (20, 20, 20))])
+    run_pair(scene, 72, 48, 7, ticks=2)
+    run_pair(scene, 40, 30, 5, ticks=2, S=3)
+
+
 def test_switch_off_gives_the_same_image():
     scene, _ = random_scene(7010, ns=300, nt=12)
     on = run_pair(scene, 64, 36, 6)
