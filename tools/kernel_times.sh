@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for tag in "$@"; do
   lib=libptss_${tag}.so; [ "$tag" = base ] && lib=libptss.so
   out=gpurun_out/kt_$tag; rm -rf $out
-  PTSS_LIBNAME=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-s1-leg --no-kernel-timing > $out.log 2>&1
+  PTSS_LIBNAME=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 bench.py ${BENCH_ARGS:-} --steps ${STEPS:-30} --warmup 3 --no-cpu-baseline --no-s1-leg --no-kernel-timing > $out.log 2>&1
   echo "== $tag"
   python3 - <<PY
 import csv
