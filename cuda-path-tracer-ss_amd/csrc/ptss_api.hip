@@ -21,7 +21,7 @@
 
 using namespace ptv;
 
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
 namespace ptss { hipError_t readCandidateHist(unsigned long long* out8); }
 #endif
 namespace {
@@ -1065,7 +1065,7 @@ int ptss_frame_lanes(const ptss_context* c, int* out) {
 int ptss_debug_phase_cycles(ptss_context* c, unsigned long long* out8) {
     if (!c || !out8) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
     HIP_TRY(ptss::readCandidateHist(out8));
     return PTSS_OK;
 #endif

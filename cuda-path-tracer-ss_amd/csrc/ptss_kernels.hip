@@ -471,7 +471,7 @@ __device__ __forceinline__ uint32_t lowBitsClamped(int cnt) { return (cnt <= 0) 
 // fails the discriminant test never changes `distance`, so visiting only the candidates, in the
 // same order, accepts exactly what the reference's full loop accepts — but the square-root path
 // runs a few times per lane instead of once per sphere for the whole wave.
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
 __device__ unsigned long long g_chist[8];
 #endif
 // diagnostic build only (-DPTSS_SHIST, tools/scatter_hist.py): how many waves execute each block of scatter(), and for how many lanes
@@ -735,6 +735,40 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
         waveLdsFence();
     }
     const unsigned long long won = best[lane];
+#ifdef PTSS_CULLSTAT   // diagnostic (tools/cull_stat.py): of the chunks a ray's line touches, how many are NOT wholly beyond its final hit?
+    {
+        const float T = (won == ~0ull) ? ptm::inf() : asF((uint32_t)(won >> 32));
+        uint32_t touched = 0, needed = 0;
+        for (int g = 0; g < L.numChunks && g < 128; g += 32) {
+            const int left = L.numChunks - g;
+            const uint32_t bits = live ? chunkMask(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
+            uint32_t rev = 0;
+            const int trips = ((left < 32 ? left : 32) + 3) >> 2;
+            for (int q = 0; q < 4 * trips; ++q) {
+                const float4 b = sc[L.offChunk + g + q];
+                const vec3 v = o - xyz(b);
+                const float dv = dot(d, v), vv = dot(v, v), a = -dv - T;
+                const bool ahead = unitDir && (a > 0.0f) && ((a * a) * (1.0f - 2e-5f) > b.w + kAccelMu * vv);
+                rev |= ahead ? 0u : (1u << q);
+            }
+            touched += (uint32_t)__builtin_popcount(bits);
+            needed += (uint32_t)__builtin_popcount(bits & rev);
+        }
+        uint32_t st = 0, sn = 0, hits = 0;
+        for (uint32_t bit = 0; bit < 7; ++bit) {
+            st += (uint32_t)__popcll(__ballot((touched >> bit) & 1u)) << bit;
+            sn += (uint32_t)__popcll(__ballot((needed >> bit) & 1u)) << bit;
+        }
+        hits = (uint32_t)__popcll(__ballot(live && won != ~0ull));
+        const uint32_t rays = (uint32_t)__popcll(__ballot(live));
+        if (lane == 0) {
+            atomicAdd(&g_chist[0], (unsigned long long)st);
+            atomicAdd(&g_chist[1], (unsigned long long)sn);
+            atomicAdd(&g_chist[2], (unsigned long long)rays);
+            atomicAdd(&g_chist[3], (unsigned long long)hits);
+        }
+    }
+#endif
     if (live && won != ~0ull) {
         const int pos = posOf[0xffffffffu - (uint32_t)won];
         float t;
@@ -2022,7 +2056,7 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
     return hipGetLastError();
 }
 
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST)
+#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
 hipError_t readCandidateHist(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chist), 64); }
 #endif
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
