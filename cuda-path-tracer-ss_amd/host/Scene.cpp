@@ -47,8 +47,8 @@ Scene::~Scene() {}
 // ARGUMENTS — vec3(rnd(5.0f) - 2.5f, rnd(5.0f) - 2.5f, rnd(7.0f) - 9.0f) (Scene.cpp:161, 219) — and C++ leaves the
 // evaluation order of function arguments unspecified (MSVC commonly evaluates them right to left). The generators here
 // draw x, then y, then z (left to right), so the "same spheres every time" layout of the default / mixed / lambert
-// presets is self-consistent but may be the reference's with x and z draws swapped; nothing the reference holds can
-// decide it (its image.tga shows the defined spheres of the Cornell preset, which draw nothing). Statistically the two
+// presets is self-consistent but may be the reference's with x and z draws swapped (`positionDrawsRightToLeft`, preset
+// suffix "@rtl", builds that other layout); nothing the reference holds can decide it (its image.tga shows the defined spheres of the Cornell preset, which draw nothing). Statistically the two
 // layouts are the same scene: 20 spheres of the same size distribution in the same box.
 int Scene::nextRand() {
     randState = randState * 214013u + 2531011u;
@@ -110,9 +110,16 @@ void Scene::addRandomGlassSpheres(const size_t numSpheres) {
     materialsVec.push_back(glass(v3(0.75f, 0.0f, 0.75f)));  // "green glass"
     for (size_t i = 0; i < numSpheres; ++i) {
         burn(3);
-        const float x = rnd(5.0f) - 2.5f;
-        const float y = rnd(5.0f) - 2.5f;
-        const float z = rnd(7.0f) - 9.0f;
+        float x, y, z;
+        if (positionDrawsRightToLeft) {  // the other legal order of vec3(...)'s arguments (see nextRand)
+            z = rnd(7.0f) - 9.0f;
+            y = rnd(5.0f) - 2.5f;
+            x = rnd(5.0f) - 2.5f;
+        } else {
+            x = rnd(5.0f) - 2.5f;
+            y = rnd(5.0f) - 2.5f;
+            z = rnd(7.0f) - 9.0f;
+        }
         const float r = rnd(1.0f) + 0.2f;
         spheresVec.push_back(Sphere(v3(x, y, z), r, first + (int)(i % 3)));
     }
@@ -126,9 +133,16 @@ void Scene::addRandomSpheres(const size_t numSpheres) {
     materialsVec.push_back(cookTorrance(v3(0.1f, 1.0f, 0.1f), v3(0.2f, 1.0f, 0.2f), 0.5f));
     for (size_t i = 0; i < numSpheres; ++i) {
         burn(2);
-        const float x = rnd(5.0f) - 2.5f;
-        const float y = rnd(5.0f) - 2.5f;
-        const float z = rnd(7.0f) - 9.0f;
+        float x, y, z;
+        if (positionDrawsRightToLeft) {  // the other legal order of vec3(...)'s arguments (see nextRand)
+            z = rnd(7.0f) - 9.0f;
+            y = rnd(5.0f) - 2.5f;
+            x = rnd(5.0f) - 2.5f;
+        } else {
+            x = rnd(5.0f) - 2.5f;
+            y = rnd(5.0f) - 2.5f;
+            z = rnd(7.0f) - 9.0f;
+        }
         const float r = rnd(1.0f) + 0.2f;
         spheresVec.push_back(Sphere(v3(x, y, z), r, first + (int)(i % 3)));
     }
@@ -219,7 +233,14 @@ void Scene::makeLambertOnly() {
     }
 }
 
-bool Scene::buildPreset(const std::string& name) {
+bool Scene::buildPreset(const std::string& preset) {
+    // "<name>@rtl": the reference's random-sphere generators with their position arguments drawn right to left
+    std::string name = preset;
+    const size_t at = name.find("@rtl");
+    if (at != std::string::npos && at + 4 == name.size()) {
+        positionDrawsRightToLeft = true;
+        name.erase(at);
+    }
     if (name == "default") {  // C1 literal default, also the geometry of C2
         build();
     } else if (name == "cornell") {  // C1 as BASELINE words it; matches CudaTracer/image.tga

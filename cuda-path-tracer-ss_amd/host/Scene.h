@@ -32,7 +32,10 @@ public:
 
     // --- additions -------------------------------------------------------------------------
     // "default" | "cornell" | "lambert" | "mixed" | "stress" | "pointlight"; false if unknown.
+    // A "@rtl" suffix (e.g. "default@rtl") draws the random spheres' position arguments right to left (z, y, x): the order
+    // C++ leaves unspecified at Scene.cpp:161, 219 of the reference and MSVC commonly takes; default: left to right.
     bool buildPreset(const std::string& name);
+    bool positionDrawsRightToLeft = false;
     void addSphereField(size_t numSpheres, float halfXY, float zNear, float zFar, float rMin, float rMax);
     void makeLambertOnly();
     ptss_scene_desc desc(vec3 defaultColor = v3(0)) const;

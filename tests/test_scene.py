@@ -60,6 +60,33 @@ def test_msvc_rand_sequence_drives_the_spheres():
     assert s.spheres[0].position.x == x
 
 
+def test_right_to_left_argument_order_is_available():
+    """Scene.cpp:161, 219 draw a sphere's coordinates as the ARGUMENTS of vec3(...): their evaluation order is unspecified in
+    C++ (MSVC commonly goes right to left). The presets draw x, y, z; "<preset>@rtl" builds the other layout: the first
+    position draw lands in z (range 7), the third in x, radii and materials stay where they were."""
+    st = 1
+    def rnd():
+        nonlocal st
+        st = (st * 214013 + 2531011) & 0xFFFFFFFF
+        return (st >> 16) & 0x7FFF
+    rnd(); rnd()
+    first, second, third = (np.float32(rnd()) for _ in range(3))
+    a, b = ptss.Scene("default"), ptss.Scene("default@rtl")
+    assert len(a.spheres) == len(b.spheres) == 20
+    assert b.spheres[0].position.z == np.float32(7.0) * first / np.float32(32767) - np.float32(9.0)
+    assert b.spheres[0].position.y == np.float32(5.0) * second / np.float32(32767) - np.float32(2.5)
+    assert b.spheres[0].position.x == np.float32(5.0) * third / np.float32(32767) - np.float32(2.5)
+    assert a.spheres[0].position.y == b.spheres[0].position.y and a.spheres[0].position.x != b.spheres[0].position.x
+    for p, q in zip(a.spheres, b.spheres):
+        assert p.radius == q.radius and p.materialIdx == q.materialIdx
+    m, n = ptss.Scene("mixed"), ptss.Scene("mixed@rtl")
+    assert len(m.spheres) == len(n.spheres) == 22
+    for p, q in zip(m.spheres[20:], n.spheres[20:]):     # the defined spheres draw nothing
+        assert (p.position.x, p.position.y, p.position.z) == (q.position.x, q.position.y, q.position.z)
+    with pytest.raises(Exception):
+        ptss.Scene("default@ltr")
+
+
 def test_mirror_box_geometry():
     s = ptss.Scene("default")
     t = s.triangles
