@@ -249,6 +249,12 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     for (size_t i = 0; i < s.numAreaLights; ++i)
         if (!finite3(s.areaLights[i].power)) L.neeSkipSafe = 0;
     L.sphereBounded = geometryBounded(s) ? 1 : 0;  // see SceneLayout::sphereBounded
+    {   // see SceneLayout::neePairs: at least two lights, and at least four of five primitives wear a diffusely reflecting material
+        size_t diffuse = 0;
+        for (size_t i = 0; i < s.numSpheres; ++i) diffuse += s.materials[s.spheres[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
+        for (size_t i = 0; i < s.numTriangles; ++i) diffuse += s.materials[s.triangles[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
+        L.neePairs = (L.sphereBounded && s.numPointLights + s.numAreaLights >= 2 && 5 * diffuse >= 4 * (s.numSpheres + s.numTriangles)) ? 1 : 0;
+    }
     L.triDetBounded = 1;  // see SceneLayout::triDetBounded
     for (size_t i = 0; i < s.numTriangles; ++i) {
         const ptss_triangle& t = s.triangles[i];

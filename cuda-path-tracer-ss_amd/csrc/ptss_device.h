@@ -100,6 +100,9 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_TRI_STRAIGHT 2
 #endif
 // 1: scatter evaluates the Snell / Fresnel terms only for lanes whose material reads them
+#ifndef PTSS_NEE_PAIRS
+#define PTSS_NEE_PAIRS 1   // the two shadow segments of an NEE round share one queue entry and their origin terms (pairAnyHit)
+#endif
 #ifndef PTSS_FRESNEL_SKIP
 #define PTSS_FRESNEL_SKIP 1
 #endif
@@ -156,6 +159,10 @@ struct SceneLayout {
     int neeSkipSafe;    // 1: light powers and diffuse colours are finite, so zero Lambert terms are exactly +-0
     int sphereBounded;  // 1: every |coordinate| <= 1e15 and every sphere radius in [1e-12, 1e15]: the sphere candidate tests may take
                         //    the two-instructions-shorter discriminant form (ptss_kernels.hip shiftInSphere<true>) while the camera is in range
+    int neePairs;       // 1: at least two lights and at least four of five primitives reflect diffusely (diffAvg > 0): a lit point then
+                        //    nearly always needs both of its shadow segments, and the kernels that test the pair together (shared origin
+                        //    terms, pairAnyHit) pay: +4.8 % on configs[1]'s scene; with specular-only materials about the scene many entries
+                        //    hold one segment and they do not: -1.4 % on configs[2]'s
     int triDetBounded;  // 1: every triangle has |e1| |e2| <= 2^100 (finite), so |det| = |e1 . (d x e2)| < 2^126 whenever
                         //    |d|^2 < 2^30 — the closest-hit triangle loop may then use the reciprocal's fast path unguarded
 };

@@ -1123,6 +1123,113 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
     return occluded || __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
+#if PTSS_NEE_PAIRS
+// ---- lineOfSight for the TWO segments a surface point sends to the two lights of an NEE round. They share their origin,
+// and so everything the tests compute from origin and primitive alone: a sphere's v = o - centre and c = |v|^2 - r^2
+// (7 of its 13 / 15 instructions), a triangle's s = o - v0, r = s x e1 and e2 . r (12 of the ~32 up to the distance test).
+// Each segment's own part is the scalar test's, on the same operands in the same order, so the two verdicts are the ones
+// two separate queue entries would get. kSplit: 1 << shift lanes share an entry, lane `sub` takes primitives sub, sub + g, ...
+// (anyHitSplit's scheme); otherwise one lane per entry and broadcast rows. liveA / liveB: the segment exists and is needed.
+template <bool kBounded, bool kSplit>
+__device__ __forceinline__ void pairAnyHit(const float4* sc, const SceneLayout& L, vec3 lo, vec3 wA, float dA, bool liveA, vec3 wB, float dB,
+                                           bool liveB, int shift, int sub, bool& occA, bool& occB) {
+    occA = false;
+    occB = false;
+    const int g = kSplit ? (1 << shift) : 1;
+    const int sphereSteps = kSplit ? ((L.numSpheres + g - 1) >> shift) : L.numSpheres;
+    for (int base = 0; base < sphereSteps; base += 32) {
+        const int cnt = (sphereSteps - base < 32) ? (sphereSteps - base) : 32;
+        const int trips = (cnt + 1) >> 1;
+        uint32_t revA = 0, revB = 0;
+        for (int t = 0; t < trips; ++t) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int step = base + 2 * t + u;
+                const float4 sp = kSplit ? sc[L.offSphere + ((step << shift) + sub)] : sc[L.offSphere + step];
+                const vec3 v = lo - xyz(sp);
+                const float c = dot(v, v) - sp.w;
+                const float hA = dot(wA, v), hB = dot(wB, v);
+                if constexpr (kBounded) {
+                    shiftInMayHit(revA, hA * hA, c);
+                    shiftInMayHit(revB, hB * hB, c);
+                } else {
+                    const float c4 = 4 * c, bA = hA * 2, bB = hB * 2;
+                    shiftInMayHit(revA, bA * bA, c4);
+                    shiftInMayHit(revB, bB * bB, c4);
+                }
+            }
+        }
+        const uint32_t valid = kSplit ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : lowBits(cnt);
+        uint32_t maskA = (__builtin_bitreverse32(revA) >> (32 - 2 * trips)) & ((liveA && !occA) ? valid : 0u);
+        uint32_t maskB = (__builtin_bitreverse32(revB) >> (32 - 2 * trips)) & ((liveB && !occB) ? valid : 0u);
+        while (maskA != 0) {
+            const int j = __builtin_ctz(maskA);
+            maskA &= maskA - 1;
+            float t;
+            if (sphereTest(sc[L.offSphere + (kSplit ? (((base + j) << shift) + sub) : (base + j))], lo, wA, dA, t)) {
+                occA = true;
+                maskA = 0;
+            }
+        }
+        while (maskB != 0) {
+            const int j = __builtin_ctz(maskB);
+            maskB &= maskB - 1;
+            float t;
+            if (sphereTest(sc[L.offSphere + (kSplit ? (((base + j) << shift) + sub) : (base + j))], lo, wB, dB, t)) {
+                occB = true;
+                maskB = 0;
+            }
+        }
+    }
+    unsigned long long needA = __ballot(liveA && !occA), needB = __ballot(liveB && !occB);
+    unsigned long long blockedA = 0ull, blockedB = 0ull;
+    const int triSteps = kSplit ? ((L.numTriangles + g - 1) >> shift) : L.numTriangles;
+    for (int k = 0; k < triSteps; ++k) {
+        if ((needA | needB) == 0ull) break;
+        const int idx = kSplit ? ((k << shift) + sub) : k;
+        const bool in = !kSplit || idx < L.numTriangles;
+        const TriRows tr = loadTri(sc + L.offTri + 3 * (in ? idx : 0));
+        const unsigned long long inMask = kSplit ? maskOf(in) : ~0ull;
+        const vec3 v0 = xyz(tr.a), e1 = xyz(tr.b), e2 = xyz(tr.c);
+        const vec3 sv = lo - v0;               // shared by the two segments (Primitives.h:46-49)
+        const vec3 r = cross(sv, e1);
+        const float e2r = dot(e2, r);
+        if (needA != 0ull) {
+            const vec3 q = cross(wA, e2);
+            const float det = dot(e1, q);
+            const float inverseDet = triRcp(det);
+            const float dist = e2r * inverseDet;
+            const unsigned long long pass = needA & inMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > dA));
+            if (pass != 0ull) {
+                const float b1 = dot(sv, q) * inverseDet;
+                const float b2 = dot(wA, r) * inverseDet;
+                const float b0 = 1.0f - (b1 + b2);
+                const unsigned long long hit = pass & maskOf(!(b0 < 0)) & maskOf(!(b1 < 0)) & maskOf(!(b2 < 0));
+                blockedA |= hit;
+                needA &= ~hit;
+            }
+        }
+        if (needB != 0ull) {
+            const vec3 q = cross(wB, e2);
+            const float det = dot(e1, q);
+            const float inverseDet = triRcp(det);
+            const float dist = e2r * inverseDet;
+            const unsigned long long pass = needB & inMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > dB));
+            if (pass != 0ull) {
+                const float b1 = dot(sv, q) * inverseDet;
+                const float b2 = dot(wB, r) * inverseDet;
+                const float b0 = 1.0f - (b1 + b2);
+                const unsigned long long hit = pass & maskOf(!(b0 < 0)) & maskOf(!(b1 < 0)) & maskOf(!(b2 < 0));
+                blockedB |= hit;
+                needB &= ~hit;
+            }
+        }
+    }
+    occA = occA || __builtin_amdgcn_inverse_ballot_w64(blockedA);
+    occB = occB || __builtin_amdgcn_inverse_ballot_w64(blockedB);
+}
+#endif
+
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
 __device__ __forceinline__ void addLambertTerm(vec3& radiance, float cosI, vec3 power, float distance2,
                                                float4 diffuse /* colour, diffAvg */) {
@@ -1534,10 +1641,11 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // eye ray in registers (no ray pool read) and intersects with the camera-origin precomputes.
 // kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
 // that scenes without it run exactly the code they ran before.
-template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded>
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairsWanted>
 __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
                                            const TileMap& tile, const EyeParams& eye) {
     extern __shared__ float4 lds[];
+    constexpr bool kPairs = PTSS_NEE_PAIRS && kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
     if constexpr (kFirst) {
@@ -1661,11 +1769,15 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
             uint32_t queued = 0;  // wave-uniform
             bool need[kNeeLights];
             float cosL[kNeeLights], distance2[kNeeLights];
+            [[maybe_unused]] vec3 pairW[kNeeLights];      // PTSS_NEE_PAIRS: the round's segments stay in registers until both are known
+            [[maybe_unused]] float pairReach[kNeeLights];
 #pragma unroll
             for (int k = 0; k < kNeeLights; ++k) {
                 need[k] = false;
                 cosL[k] = 0;
                 distance2[k] = 0;
+                pairW[k] = v3(0, 0, 0);
+                pairReach[k] = 0;
                 const int li = l0 + k;
                 if (li >= numLights) continue;  // uniform
                 vec3 lo = v3(0, 0, 0), w_i = v3(0, 0, 0);
@@ -1699,6 +1811,11 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                     lo = point + (ptm::kRayBump * normal);
                     distance -= 2 * ptm::kRayBump;
                 }
+                if constexpr (kPairs) {
+                    pairW[k] = w_i;
+                    pairReach[k] = distance;
+                    continue;
+                }
                 const unsigned long long m = __ballot(need[k]);
                 if (need[k]) {
                     const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1ull));
@@ -1719,6 +1836,65 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
             if (lane == 0) atomicAdd(&fb.stamps[queued == 0 ? 0 : (queued <= 8 ? 1 : (queued <= 16 ? 2 : (queued <= 32 ? 3 : (queued <= 64 ? 4 : (queued <= 72 ? 5 : (queued <= 96 ? 6 : 7))))))], 1ull);
 #endif
             PTSS_STAMP(2);  // surfel + light sampling + enqueue
+#if PTSS_NEE_PAIRS
+            if constexpr (kPairs) {
+                // One entry per lane that needs either segment: origin, the two directions and reaches, owner lane | need bits << 8
+                // (12 planes of 64). A pass is sized by what it holds: 49+ entries one lane each, fewer -> 32 / 16 / 8 entries
+                // with 2 / 4 / 8 lanes sharing the primitive list.
+                constexpr int kPairCap = 64;
+                const bool needAny = need[0] || need[1];
+                const unsigned long long m = __ballot(needAny);
+                const uint32_t pairs = (uint32_t)__popcll(m);
+                uint32_t* pairOwner = reinterpret_cast<uint32_t*>(wq + 11 * kPairCap);
+                if (needAny) {
+                    const uint32_t slot = __popcll(m & ((1ull << lane) - 1ull));
+                    const vec3 lo = point + (ptm::kRayBump * normal);
+                    wq[0 * kPairCap + slot] = lo.x;
+                    wq[1 * kPairCap + slot] = lo.y;
+                    wq[2 * kPairCap + slot] = lo.z;
+                    wq[3 * kPairCap + slot] = pairW[0].x;
+                    wq[4 * kPairCap + slot] = pairW[0].y;
+                    wq[5 * kPairCap + slot] = pairW[0].z;
+                    wq[6 * kPairCap + slot] = pairReach[0];
+                    wq[7 * kPairCap + slot] = pairW[1].x;
+                    wq[8 * kPairCap + slot] = pairW[1].y;
+                    wq[9 * kPairCap + slot] = pairW[1].z;
+                    wq[10 * kPairCap + slot] = pairReach[1];
+                    pairOwner[slot] = lane | ((need[0] ? 1u : 0u) << 8) | ((need[1] ? 1u : 0u) << 9);
+                    wqAnswer[0 * 64 + lane] = 0;
+                    wqAnswer[1 * 64 + lane] = 0;
+                }
+                waveLdsFence();
+                for (uint32_t e0 = 0; e0 < pairs;) {
+                    const uint32_t rem = pairs - e0;
+                    const uint32_t units = (rem + 7u) >> 3;
+                    const int chunkLog = (units >= 7u) ? 6 : (units >= 4u ? 5 : (units >= 2u ? 4 : 3));
+                    const int shift = 6 - chunkLog;
+                    const uint32_t mine = lane >> shift;
+                    const uint32_t sub = lane & ((1u << shift) - 1u);
+                    const bool have = mine < rem;
+                    const uint32_t es = have ? e0 + mine : 0u;
+                    const vec3 lo = v3(wq[0 * kPairCap + es], wq[1 * kPairCap + es], wq[2 * kPairCap + es]);
+                    const vec3 wA = v3(wq[3 * kPairCap + es], wq[4 * kPairCap + es], wq[5 * kPairCap + es]);
+                    const float dA = wq[6 * kPairCap + es];
+                    const vec3 wB = v3(wq[7 * kPairCap + es], wq[8 * kPairCap + es], wq[9 * kPairCap + es]);
+                    const float dB = wq[10 * kPairCap + es];
+                    const uint32_t ow = pairOwner[es];
+                    const bool liveA = have && ((ow >> 8) & 1u) != 0u, liveB = have && ((ow >> 9) & 1u) != 0u;
+                    bool occA, occB;
+                    if (shift == 0) pairAnyHit<kBounded, false>(sc, L, lo, wA, dA, liveA, wB, dB, liveB, 0, 0, occA, occB);
+                    else pairAnyHit<kBounded, true>(sc, L, lo, wA, dA, liveA, wB, dB, liveB, shift, (int)sub, occA, occB);
+                    const unsigned long long verdictsA = __ballot(occA), verdictsB = __ballot(occB);
+                    const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
+                    if (have && sub == 0u) {
+                        if ((verdictsA & group) != 0ull) wqAnswer[0 * 64 + (ow & 63u)] = 1;
+                        if ((verdictsB & group) != 0ull) wqAnswer[1 * 64 + (ow & 63u)] = 1;
+                    }
+                    e0 += 1u << chunkLog;
+                }
+            } else
+#endif
+            {
 #if PTSS_SPLIT_SPARSE
             // Passes over the wave's queue, each sized by what is left (wave-uniform): 49+ segments -> a dense pass,
             // one lane per segment (anyHit, broadcast rows); fewer -> a chunk of 32 / 16 / 8 segments with 2 / 4 / 8
@@ -1770,6 +1946,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 }
             }
 #endif
+            }
             waveLdsFence();
             PTSS_STAMP(3);  // dense shadow passes
 #pragma unroll
@@ -1897,10 +2074,10 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
     }
 }
 
-template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded>
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairs>
 __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES))) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
     FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
-    bounceBody<kLast, kSceneInLds, kFirst, kAccel, kBounded>(fb, sceneBlob, L, bounce, tile, eye);
+    bounceBody<kLast, kSceneInLds, kFirst, kAccel, kBounded, kPairs>(fb, sceneBlob, L, bounce, tile, eye);
     // frame lanes: "this workgroup of bounce `bounce` has ended" (every workgroup, also one that had nothing to do) — the
     // peers' loop guard of bounce + 1 waits for the whole grid (frameLiveCount). The survivor counters were raised by
     // returning device-scope atomics, so they have been performed when a wave gets here, and the barrier collects the
@@ -2047,11 +2224,11 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
     return hipGetLastError();
 }
 
-template <bool kLast, bool kLds, bool kFirst, bool kAccel, bool kBounded>
+template <bool kLast, bool kLds, bool kFirst, bool kAccel, bool kBounded, bool kPairs>
 static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout,
                                 int bounce, int gridBlocks, const TileMap& tile, const EyeParams& eye) {
     const size_t lds = bounceLdsBytes(layout, kLds);
-    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst, kAccel, kBounded>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
+    hipLaunchKernelGGL((bounceKernel<kLast, kLds, kFirst, kAccel, kBounded, kPairs>), dim3(gridBlocks), dim3(kBlock), lds, st, fb, sceneBlob, layout, bounce,
                        tile, eye);
     return hipGetLastError();
 }
@@ -2068,9 +2245,10 @@ hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sc
     const bool isFirst = bounce == 0;
 #define PTSS_GO(a, b, c)                                                                                   \
     do {                                                                                                   \
-        if (layout.accelSpheres) return launchBounceT<a, b, c, true, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
-        if (bounded) return launchBounceT<a, b, c, false, true>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);           \
-        return launchBounceT<a, b, c, false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);                       \
+        if (layout.accelSpheres) return launchBounceT<a, b, c, true, false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
+        if (bounded && layout.neePairs) return launchBounceT<a, b, c, false, true, true>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye); \
+        if (bounded) return launchBounceT<a, b, c, false, true, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);     \
+        return launchBounceT<a, b, c, false, false, false>(st, fb, sceneBlob, layout, bounce, gridBlocks, tile, eye);                 \
     } while (0)
     if (sceneInLds) {
         if (isFirst) { if (isLast) PTSS_GO(true, true, true); else PTSS_GO(false, true, true); }
@@ -2092,14 +2270,14 @@ int bounceOccupancyBlocksPerCU(const SceneLayout& layout, bool sceneInLds, bool 
     int a = 0;
     hipError_t e;
     if (accel)
-        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, true, false>, kBlock, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, true, false>, kBlock, lds);
-    else if (layout.sphereBounded)
-        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, true>, kBlock, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, true>, kBlock, lds);
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, true, false, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, true, false, false>, kBlock, lds);
+    else if (layout.sphereBounded)   // (the paired-shadow instantiations have the same launch bounds)
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, true, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, true, false>, kBlock, lds);
     else
-        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, false>, kBlock, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, false>, kBlock, lds);
+        e = sceneInLds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, true, false, false, false, false>, kBlock, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bounceKernel<false, false, false, false, false, false>, kBlock, lds);
     return e == hipSuccess ? a : 0;
 }
 

@@ -167,6 +167,21 @@ def test_sphere_test_forms_switch_with_the_geometry_and_the_camera():
     r.close()
 
 
+def test_diffuse_scenes_pair_their_shadow_segments():
+    """Scenes whose primitives are (at least four in five) diffuse, with two or more lights, run the kernels that carry the two
+    shadow segments of a surface point as ONE queue entry and test them together (SceneLayout::neePairs, pairAnyHit). Three
+    lights: the second round holds a single segment per entry; a point light inside the scene; lanes whose one light is
+    below the horizon. Against the oracle, bit for bit, dense passes (full frames) and split ones (tiny frames)."""
+    sph = [((-1.8, -0.3, -4.2), 0.7, CREAM), ((0.1, -0.4, -3.4), 0.6, RED), ((1.7, -0.2, -4.6), 0.8, GREEN), ((0.2, 0.9, -5.5), 0.5, CREAM),
+           ((-0.9, 1.6, -4.8), 0.4, GREEN), ((1.1, 1.4, -3.9), 0.35, RED), ((0, -0.7, -2.2), 0.3, CREAM)]
+    scene = build(spheres=sph, triangles=FLOOR + LAMP, area=[((50, 50, 50), 2)],
+                  point=[((-2.5, 2.0, -2.0), (30, 30, 30)), ((0.3, 0.2, -4.4), (6, 6, 6))])
+    check(scene, 64, 40, 6, ticks=3)
+    check(scene, 17, 9, 5, ticks=2, S=3)
+    two = build(spheres=sph, triangles=FLOOR + LAMP, area=[((50, 50, 50), 2)], point=[((-2.5, 2.0, -2.0), (30, 30, 30))])
+    check(two, 48, 32, 8, ticks=2, S=2)
+
+
 def test_walls_made_of_giant_spheres():
     """The smallpt way of building a room: walls are spheres of radius 1e5. Leaving such a wall, c = |v|^2 - r^2 is ~2 r bump =
     20 against b^2 ~ 4e10 — below half an ulp of b^2, so the discriminant rounds to b^2, one root comes out as exactly 0 and

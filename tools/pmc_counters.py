@@ -51,7 +51,7 @@ if insts:
     import re
 
     def targs(n):  # <kLast, kSceneInLds, kFirst, kAccel, kBounded>
-        m = re.search(r"bounceKernel<(\w+), (\w+), (\w+), (\w+)(?:, (\w+))?>", n)
+        m = re.search(r"bounceKernel<(\w+), (\w+), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", n)
         return m.groups() if m else None
     mid = {k: v for k, v in insts.items() if targs(names[k]) and targs(names[k])[0] == "false" and targs(names[k])[2] == "false"}
     try:
