@@ -520,13 +520,13 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     if (numLanes < 0 || numLanes > ptss::kMaxLanes) return (delete c, fail(PTSS_EINVAL, "frameLanes must be in [0, 4]"));
     {
         const unsigned long long rays = (unsigned long long)c->numPixels * c->samples;
-        // measured (tools/lanes_bench.py, Mrays/s with 1 / 2 / 3 / 4 lanes): 1920x1080 S = 1 (2.1 M rays per pass) 13,500 /
-        // 15,000-15,900 / 14,700 / 9,800; 3840x2160 1,024 spheres S = 1 (8.3 M) 4,000 / 4,250 / 4,410 / 3,310; 1280x720 S = 1
-        // (0.9 M) 9,280-9,360 / 9,590-10,250 / 9,450 / 5,150 in one run, 9,390 / 8,470-9,430 in others — no consistent gain; 800x600
-        // (0.48 M) 7,270-7,330 / 7,230-7,690; 512x512 (0.26 M) 4,600-4,650 / 4,030-4,450: below ~0.3 ms a pass is ten launch
-        // latencies, nothing to overlap; 1920x1080 S = 40 (83 M) 17,000 / 17,150 / 16,970 / 16,620. Four lanes (five streams with
-        // the caller's) share hardware queues and serialise.
-        if (numLanes == 0) numLanes = (rays >= (1ull << 20) && rays <= (1ull << 24)) ? 2 : 1;
+        // measured (tools/lanes_bench.py / tools/s1_modes.py, Mrays/s with 1 / 2 lanes, one sample per tick, with the lanes coupled on
+        // the device — flushKernel's finished-frames counters): 1920x1080 (2.1 M rays per pass) 13,800 / 16,300; 3840x2160, 1,024 spheres
+        // (8.3 M) 4,110 / 4,360 (three lanes 4,580, four 3,470); 1280x720 (0.92 M) 10,010 / 11,160; 1024x576 (0.59 M) 8,050 / 9,090;
+        // 800x600 (0.48 M) 7,490 / 7,900; 640x480 (0.31 M) 5,480 / 5,380; 512x512 (0.26 M) 4,730 / 4,570 — below ~0.2 ms a pass is ten launch
+        // latencies, nothing to overlap; 1920x1080 S = 40 (83 M) 17,760 / 17,750. Four lanes (five streams with the caller's) share
+        // hardware queues and serialise. (With the lanes coupled through stream events the gain at 1280x720 was inside the noise.)
+        if (numLanes == 0) numLanes = (rays >= (3ull << 17) && rays <= (1ull << 24)) ? 2 : 1;
     }
     c->lanes.resize((size_t)numLanes);
     uint32_t shardCount0[ptss::kMaxLanes][ptss::kShards] = {{0}};

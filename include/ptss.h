@@ -54,7 +54,8 @@ typedef struct ptss_render_config {
     int everySphereLoop;
     /* Frame lanes: the frame traced as K ray populations on K streams of the device, the tail of one lane's launches
      * overlapping the other lanes' kernels. The image — loop guard included — does not depend on K.
-     * 0 = chosen from the size of a pass (2 for 2^20..2^24 rays per pass, e.g. 1920x1080 at one sample per tick; else 1),
+     * 0 = chosen from the size of a pass (2 for 3*2^17..2^24 rays per pass, e.g. 800x600 ... 3840x2160 at one sample per tick;
+     * else 1),
      * 1..4 = that many. */
     int frameLanes;
 } ptss_render_config;

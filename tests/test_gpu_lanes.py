@@ -97,9 +97,12 @@ def test_automatic_lane_count():
     small = ptss.Renderer(scene, 64, 64)
     assert small.frame_lanes == 1                      # 4,096 rays per pass: one launch round, nothing to overlap
     small.close()
-    hd = ptss.Renderer(scene, 1920, 1080)
-    assert hd.frame_lanes == 2                         # 2 million: ten launches of 1-4 resident rounds each
+    hd = ptss.Renderer(scene, 1280, 720)
+    assert hd.frame_lanes == 2                         # 0.9 million: ten launches of 1-2 resident rounds each
     hd.close()
+    vga = ptss.Renderer(scene, 640, 480)
+    assert vga.frame_lanes == 1                        # 0.3 million: a pass is ten launch latencies
+    vga.close()
     wide = ptss.Renderer(scene, 1920, 1080, samples_per_pass=40)
     assert wide.frame_lanes == 1                       # 83 million rays per pass: launches are wide enough
     wide.close()
