@@ -253,7 +253,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         size_t diffuse = 0;
         for (size_t i = 0; i < s.numSpheres; ++i) diffuse += s.materials[s.spheres[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
         for (size_t i = 0; i < s.numTriangles; ++i) diffuse += s.materials[s.triangles[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
-        L.neePairs = (L.sphereBounded && s.numPointLights + s.numAreaLights >= 2 && 5 * diffuse >= 4 * (s.numSpheres + s.numTriangles)) ? 1 : 0;
+        L.neePairs = (L.sphereBounded && s.numPointLights + s.numAreaLights >= 2 && (PTSS_FORCE_PAIRS || 5 * diffuse >= 4 * (s.numSpheres + s.numTriangles))) ? 1 : 0;
     }
     L.triDetBounded = 1;  // see SceneLayout::triDetBounded
     for (size_t i = 0; i < s.numTriangles; ++i) {

@@ -100,6 +100,9 @@ constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entri
 #define PTSS_TRI_STRAIGHT 2
 #endif
 // 1: scatter evaluates the Snell / Fresnel terms only for lanes whose material reads them
+#ifndef PTSS_FORCE_PAIRS
+#define PTSS_FORCE_PAIRS 0   // measurement only: the paired any-hit in every scene with two lights
+#endif
 #ifndef PTSS_NEE_PAIRS
 #define PTSS_NEE_PAIRS 1   // the two shadow segments of an NEE round share one queue entry and their origin terms (pairAnyHit)
 #endif

@@ -1831,6 +1831,17 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 }
                 queued += (uint32_t)__popcll(m);
             }
+#ifdef PTSS_PAIRSTAT   // diagnostic (tools/pair_stat.py; built together with PTSS_CULLSTAT for the counters' plumbing)
+            {
+                const unsigned long long mb = __ballot(need[0] && need[1]), mo = __ballot(need[0] != need[1]), ml = __ballot(lit);
+                if (lane == 0) {
+                    atomicAdd(&g_chist[4], (unsigned long long)__popcll(mb));
+                    atomicAdd(&g_chist[5], (unsigned long long)__popcll(mo));
+                    atomicAdd(&g_chist[6], (unsigned long long)__popcll(ml));
+                    atomicAdd(&g_chist[7], 1ull);
+                }
+            }
+#endif
             waveLdsFence();
 #ifdef PTSS_QHIST  // diagnostic: histogram of the wave's queue length per NEE round (tools/queue_hist.py)
             if (lane == 0) atomicAdd(&fb.stamps[queued == 0 ? 0 : (queued <= 8 ? 1 : (queued <= 16 ? 2 : (queued <= 32 ? 3 : (queued <= 64 ? 4 : (queued <= 72 ? 5 : (queued <= 96 ? 6 : 7))))))], 1ull);

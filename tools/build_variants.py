@@ -12,8 +12,10 @@ spec.loader.exec_module(b)
 VARIANTS = {
     "knobs": ["PTSS_TUNING_KNOBS=1"],   # reads PTSS_GRID_CAP / PTSS_SCENE_PATH from the environment (tools/sweep_env.sh)
     "lfork": ["PTSS_LANE_ALWAYS_FORK=1"],
+    "fp": ["PTSS_FORCE_PAIRS=1"],   # the paired any-hit in every scene with two lights (what it costs configs[2]'s)
     "nopairs": ["PTSS_NEE_PAIRS=0"],   # one queue entry per shadow segment (before the paired any-hit)
     "cullstat": ["PTSS_CULLSTAT=1"],   # diagnostic: tools/cull_stat.py
+    "pairstat": ["PTSS_CULLSTAT=1", "PTSS_PAIRSTAT=1"],   # diagnostic: tools/pair_stat.py
     "wb5": ["PTSS_MINWAVES_BOUNDED=5"],   # the bounded-geometry instantiations at 5 / 7 waves per SIMD
     "wb7": ["PTSS_MINWAVES_BOUNDED=7"],
     "wb5su7": ["PTSS_MINWAVES_BOUNDED=5", "PTSS_SPHERE_UNROLL=7"],
