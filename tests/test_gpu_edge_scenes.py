@@ -182,6 +182,25 @@ def test_diffuse_scenes_pair_their_shadow_segments():
     check(two, 48, 32, 8, ticks=2, S=2)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_diffuse_scenes_with_several_lights(seed):
+    """Random all-diffuse scenes (the paired-shadow kernels, SceneLayout::neePairs) with 2-5 lights, odd and even counts,
+    lights inside the cloud of spheres, triangles at random: against the oracle, at sizes that give dense and split passes."""
+    rng = np.random.default_rng(seed)
+    mats = [CREAM, RED, GREEN]
+    sph = [((float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-0.9, 2.2)), float(rng.uniform(-7.0, -2.5))), float(rng.uniform(0.15, 0.7)),
+            mats[int(rng.integers(0, 3))]) for _ in range(int(rng.integers(5, 30)))]
+    tris = FLOOR + LAMP
+    for _ in range(int(rng.integers(0, 6))):
+        a = rng.uniform(-3, 3, size=3) + np.array([0, 0.5, -5])
+        tris = tris + [(tuple(a), tuple(a + rng.uniform(-1.5, 1.5, size=3)), tuple(a + rng.uniform(-1.5, 1.5, size=3)), mats[int(rng.integers(0, 3))])]
+    pts = [((float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.5, 2.8)), float(rng.uniform(-6.5, -1.5))), tuple(float(x) for x in rng.uniform(5, 40, size=3)))
+           for _ in range(int(rng.integers(1, 5)))]
+    scene = build(spheres=sph, triangles=tris, area=[((50, 50, 50), 2)], point=pts)
+    check(scene, int(rng.integers(40, 90)), int(rng.integers(24, 60)), int(rng.integers(2, 9)), ticks=2, S=int(rng.choice([1, 2, 5])))
+    check(scene, 13, 7, 4, ticks=2)
+
+
 def test_walls_made_of_giant_spheres():
     """The smallpt way of building a room: walls are spheres of radius 1e5. Leaving such a wall, c = |v|^2 - r^2 is ~2 r bump =
     20 against b^2 ~ 4e10 — below half an ulp of b^2, so the discriminant rounds to b^2, one root comes out as exactly 0 and
