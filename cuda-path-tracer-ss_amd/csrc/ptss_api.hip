@@ -21,8 +21,8 @@
 
 using namespace ptv;
 
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
-namespace ptss { hipError_t readCandidateHist(unsigned long long* out8); }
+#if PTSS_DIAG
+namespace ptss { hipError_t readDiagCounters(unsigned long long* out8); }
 #endif
 namespace {
 
@@ -86,7 +86,7 @@ struct ptss_context {
     hipEvent_t evFork = nullptr;            // several lanes: the caller's stream has reached this frame
     int countParity = 0;                    // which of a lane's two count buffers the next frame uses
     uint32_t* dRngHome = nullptr;
-    unsigned long long* dTotal = nullptr;   // [0 .. kMaxLanes) ray-bounce totals per lane, [kMaxLanes .. +8) diagnostic phase stamps,
+    unsigned long long* dTotal = nullptr;   // [0 .. kMaxLanes) ray-bounce totals per lane, [kMaxLanes .. +8) unused,
                                             // then one word: guard timeouts (must stay 0)
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
@@ -253,7 +253,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         size_t diffuse = 0;
         for (size_t i = 0; i < s.numSpheres; ++i) diffuse += s.materials[s.spheres[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
         for (size_t i = 0; i < s.numTriangles; ++i) diffuse += s.materials[s.triangles[i].materialIdx].diffAvg > 0.0f ? 1 : 0;
-        L.neePairs = (L.sphereBounded && s.numPointLights + s.numAreaLights >= 2 && (PTSS_FORCE_PAIRS || 5 * diffuse >= 4 * (s.numSpheres + s.numTriangles))) ? 1 : 0;
+        L.neePairs = (L.sphereBounded && s.numPointLights + s.numAreaLights >= 2 && 5 * diffuse >= 4 * (s.numSpheres + s.numTriangles)) ? 1 : 0;
     }
     L.triDetBounded = 1;  // see SceneLayout::triDetBounded
     for (size_t i = 0; i < s.numTriangles; ++i) {
@@ -357,7 +357,6 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4*
     fb.shardCount0 = ln.dShardCount0;
     fb.lastCounts = ln.dLastCounts;
     fb.totalRayBounces = c->dTotal + laneIdx;
-    fb.stamps = c->dTotal + ptss::kMaxLanes;
     fb.guardTimeouts = reinterpret_cast<uint32_t*>(c->dTotal + ptss::kMaxLanes + 8);
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
@@ -1068,14 +1067,14 @@ int ptss_frame_lanes(const ptss_context* c, int* out) {
     return PTSS_OK;
 }
 
-int ptss_debug_phase_cycles(ptss_context* c, unsigned long long* out8) {
+int ptss_debug_counters(ptss_context* c, unsigned long long* out8) {
     if (!c || !out8) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
-    HIP_TRY(ptss::readCandidateHist(out8));
-    return PTSS_OK;
+#if PTSS_DIAG
+    HIP_TRY(ptss::readDiagCounters(out8));
+#else
+    for (int k = 0; k < 8; ++k) out8[k] = 0ull;   // the shipped library carries no counter (ptss_diag.h)
 #endif
-    HIP_TRY(hipMemcpy(out8, c->dTotal + ptss::kMaxLanes, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTSS_OK;
 }
 

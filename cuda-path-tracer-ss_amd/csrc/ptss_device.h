@@ -31,97 +31,40 @@ enum RayPlane : int {
 };
 constexpr int kHomeWords = 8;     // per-pixel RNG home record: v0..v4, d, 2 pad words (32 B)
 constexpr int kMaxBounces = 64;  // counts has (kMaxBounces + 1) x kShards entries
-// Build-time tuning knobs (A/B variants are built by tools/build_variants.py; defaults are the shipped ones)
+// Build-time switches (eight; tools/build_variants.py builds A/B variants — the shipped library uses the defaults). What was
+// tried and rejected with numbers lives in profiles/README.md and in the history, not behind switches here.
 #ifndef PTSS_BLOCK
-#define PTSS_BLOCK 256
+#define PTSS_BLOCK 256    // rays per tile = threads per workgroup (128-ray tiles: -20 % at one sample per tick, profiles/README.md)
+#endif
+#ifndef PTSS_SHARDS
+#define PTSS_SHARDS 16    // pool regions / live-ray counters per bounce
+#endif
+#ifndef PTSS_CHUNK
+#define PTSS_CHUNK 16     // spheres per chunk of the many-sphere traversal; with the kd-split order (ptss_api.hip spatialOrder),
+                          // configs[4]'s scene at S = 4, same box: 4: 2,224, 8: 3,762, 16: 4,158-4,167, 32: 3,476 Mrays/s — every
+                          // lane tests every chunk bound, so halving their number is worth more than the tighter fit of smaller chunks
 #endif
 #ifndef PTSS_MINWAVES
-#define PTSS_MINWAVES 7   // __launch_bounds__ waves/SIMD: caps the bounce kernel at 72 VGPRs. With the vectorisers off (build.py) and
-                          // PTSS_DEFER_LOADS the only scratch left is in a cold IEEE-division escape block. Measured, same box:
+#define PTSS_MINWAVES 7   // __launch_bounds__ waves/SIMD of the unbounded-geometry instantiations: 72 VGPRs. Measured, same box:
                           // 5 waves (96 VGPRs) 13.3, 6 (80) 14.2, 7 (72) 14.5, 8 (64, spills) 11.4 Grays/s
 #endif
 #ifndef PTSS_MINWAVES_BOUNDED
 #define PTSS_MINWAVES_BOUNDED 6   // the instantiations for bounded scenes (SceneLayout::sphereBounded: the shorter sphere test) want 80
                                   // registers: at 7 waves the shorter test costs 3 % (32 instead of 16 B of scratch), at 6 it gains — same-box
                                   // A/B against 7 waves + the long test: c3 +0.5 %, c2 +2.3 %, one sample per tick at 1080p +2.5-3 %
-                                  // (5 waves, 96 registers: -3.5 %; with four spheres per trip in the shadow passes as well: -4.5 %)
 #endif
 #ifndef PTSS_MINWAVES_FIRST
-#define PTSS_MINWAVES_FIRST 6   // bounce 0's instantiation (eye rays fused in, camera-origin tests) has its own register budget:
-                                // at 7 waves it spills 32 B (18 scratch accesses per tile), at 6 (80 VGPRs) none —
-                                // same-box A/B: that kernel 3,035 -> 2,826 us per launch, the pass +0.9 %
+#define PTSS_MINWAVES_FIRST 6   // bounce 0's instantiation (eye rays fused in, camera-origin tests): at 7 waves it spills 32 B, at 6
+                                // (80 VGPRs) none — same-box A/B: that kernel 3,035 -> 2,826 us per launch, the pass +0.9 %
 #endif
 #ifndef PTSS_ABLATE
-#define PTSS_ABLATE 0   // measurement-only: bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
+#define PTSS_ABLATE 0   // measurement only (WRONG images): bit 0 no NEE, 1 no closest-hit loops, 2 no scatter, 3 no finishPath
 #endif
-#ifndef PTSS_WAVE_COMPACT
-#define PTSS_WAVE_COMPACT 1   // 1: per-wave compaction, no barriers; 0: per-workgroup (LDS + 2 barriers)
-#endif
-#ifndef PTSS_TRI_GUARD2
-#define PTSS_TRI_GUARD2 0
-#endif
-// 1: a ray's planes are fetched where the tile first needs them (origin/direction, then RNG, then radiance/throughput/
-// pixel) instead of all at the top: 13 fewer live registers across the closest-hit loops
-#ifndef PTSS_DEFER_LOADS
-#define PTSS_DEFER_LOADS 1
-#endif
-// 1: a pass over fewer than 64 queued shadow segments gives each segment 2, 4 or 8 lanes that share the primitive list
-#ifndef PTSS_SPLIT_SPARSE
-#define PTSS_SPLIT_SPARSE 1
-#endif
-// 1: 8-bit tone mapping through the threshold table (ptquant.h); 0: the literal clamp/pow/scale sequence
-#ifndef PTSS_QUANT_TABLE
-#define PTSS_QUANT_TABLE 1
-#endif
-// 1: many-sphere scenes regroup their (ray, chunk) work across the wave (closestSpheresRegrouped); 0: every lane walks its own chunks
-#ifndef PTSS_REGROUP
-#define PTSS_REGROUP 1
-#endif
-// 1: many-sphere scenes: shadow passes walk kWarmChunks chunks per lane, then regroup the rest (anySpheresHybrid)
-#ifndef PTSS_REGROUP_SHADOW
-#define PTSS_REGROUP_SHADOW 1
-#endif
-// 1: sphere candidate masks four spheres per trip, verdicts shifted in through the carry (sphereCandidates)
-// (bit 0: closest hit, four per trip; bits 1/2: dense / lane-split shadow passes, four per trip — these spill; bits 3/4:
-// the same two, two per trip)
-#ifndef PTSS_SPHERE_UNROLL
-#define PTSS_SPHERE_UNROLL 25
-#endif
-// 1: scene rows of which three words are used are fetched as whole 16-byte rows (ds_read_b128) instead of 12 bytes
-// (ds_read_b96). A/B switch only: for these broadcast reads the 12-byte form is the faster one (tools/microbench/loops.hip:
-// 8.4 against 14 SIMD-cycles per wave-read — the LDS-to-VGPR return path moves bytes, and 768 are fewer than 1,024)
-#ifndef PTSS_ROW128
-#define PTSS_ROW128 0
-#endif
-// 2: the closest hit's triangle loop in its lean form (triangleHybrid: reciprocal's range guard hoisted to one test per
-// query, min3 for the three weight tests, selects instead of an exec-masked accept block); 1: the same without any
-// wave-uniform exit; 0: triangleTest as in the any-hit loops
-#ifndef PTSS_TRI_STRAIGHT
-#define PTSS_TRI_STRAIGHT 2
-#endif
-// 1: scatter evaluates the Snell / Fresnel terms only for lanes whose material reads them
-#ifndef PTSS_FORCE_PAIRS
-#define PTSS_FORCE_PAIRS 0   // measurement only: the paired any-hit in every scene with two lights
-#endif
-#ifndef PTSS_NEE_PAIRS
-#define PTSS_NEE_PAIRS 1   // the two shadow segments of an NEE round share one queue entry and their origin terms (pairAnyHit)
-#endif
-#ifndef PTSS_FRESNEL_SKIP
-#define PTSS_FRESNEL_SKIP 1
-#endif
-// experiment, off: survivors leave a wave ordered by class (1: material class of the surface just left, 2: direction octant)
-#ifndef PTSS_CLASS_RANK
-#define PTSS_CLASS_RANK 0
-#endif
-#ifndef PTSS_SHARDS
-#define PTSS_SHARDS 16
+#ifndef PTSS_DIAG
+#define PTSS_DIAG 0     // diagnostic counters (ptss_diag.h; tools/*_hist.py, *_stat.py): bit 0 sphere candidates per lane, 1 scatter
+                        // blocks, 2 chunk culling, 3 shadow-segment pairs, 4 shadow-queue lengths. 0: no counter exists in the code
 #endif
 constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workgroup
-#ifndef PTSS_CHUNK
-#define PTSS_CHUNK 16   // with the kd-split order (ptss_api.hip spatialOrder), configs[5] scene at S = 4, same box:
-                        // 4: 2,224, 8: 3,762, 16: 4,158-4,167, 32: 3,476 Mrays/s — every lane tests every chunk bound, so
-                        // halving their number is worth more than the tighter fit of smaller chunks
-#endif
 constexpr int kChunkSpheres = PTSS_CHUNK;
 static_assert((kChunkSpheres & (kChunkSpheres - 1)) == 0, "chunk size must be a power of two");   // spheres per chunk of the many-sphere traversal
 constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
@@ -210,7 +153,6 @@ struct FrameBuffers {
     const uint32_t* shardCount0;  // [kShards] pixels per shard (constant per context): counts of bounce 0
     uint32_t* lastCounts;    // the previous frame's counts (copied by flushKernel before it re-arms `counts`)
     unsigned long long* totalRayBounces;
-    unsigned long long* stamps;   // [8] wave-cycles per phase, written only by -DPTSS_STAMPS diagnostic builds
     uint32_t* accum;         // uint3 per local pixel (totalPixelColors)
     float* fsum;             // float3 per local pixel or nullptr
     const float* quantTable; // the same thresholds in global memory (flushKernel has no staged scene)

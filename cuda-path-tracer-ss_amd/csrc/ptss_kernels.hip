@@ -95,7 +95,7 @@ __device__ __forceinline__ void stPlane(float* __restrict__ region, uint32_t wor
     *reinterpret_cast<float*>(reinterpret_cast<char*>(region) + (size_t)wordBytes + (size_t)plane * (kBlock * sizeof(float))) = v;
 }
 
-// PTSS_DEFER_LOADS fetches a ray's planes in the order the tile needs them, so that no plane occupies registers before
+// A tile fetches a ray's planes in the order it needs them, so that no plane occupies registers before
 // its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
 // throughput / pixel for the update at the end. `block` = the tile's block (wave-uniform), w = the ray's lane in it.
 __device__ __forceinline__ void loadRayGeometry(const float* __restrict__ block, uint32_t w, RayRegs& r) {
@@ -142,16 +142,9 @@ __device__ __forceinline__ void storeRay(float* __restrict__ region, uint32_t sl
 }
 
 // ---- Sphere::intersectRay, Primitives.h:107-175. sp = {centre, radius^2}. ---------------------
-// Split at the reference's first exit: sphereMayHit is `!(discriminent < 0)` (Primitives.h:117-118),
-// sphereTest is the whole test; both evaluate b, c and the discriminant with the same operations.
-__device__ __forceinline__ bool sphereMayHit(float4 sp, vec3 o, vec3 d) {
-    const vec3 v = o - xyz(sp);
-    const float b = dot(d, v) * 2;
-    const float c = dot(v, v) - sp.w;
-    const float disc = (b * b) - 4 * c;
-    return !(disc < 0);
-}
-
+// The reference's first exit, `discriminent < 0` (Primitives.h:117-118), is what the candidate masks below decide for up to
+// 32 spheres at a time (shiftInSphere); sphereTest is the whole test, for the candidates. Both evaluate b, c and the
+// discriminant with the same operations.
 // Returns the accepted distance in t; `limit` is the running `distance`.
 __device__ __forceinline__ bool sphereTest(float4 sp, vec3 o, vec3 d, float limit, float& t) {
     const vec3 v = o - xyz(sp);
@@ -190,27 +183,15 @@ struct TriHit {
 struct TriRows {  // one staged triangle: {v0, bits(materialIdx)}, {e1, 0}, {e2, 0}
     float4 a, b, c;
 };
-// The tests use three of a row's four words, and left alone hipcc narrows each fetch to ds_read_b96 — which the LDS
-// serves 8 lanes per cycle (8 cycles per wave-instruction, 96 B/clk/CU) against 16 lanes per cycle for ds_read_b128
-// (4 cycles; MI355X_MICROARCH.md, LDS table). Three rows per triangle, every triangle, every query: the 16-byte form
-// halves the LDS time of the triangle loops. The empty asm statement "uses" the fourth word (no instruction is
-// emitted), so the fetch cannot be narrowed.
-__device__ __forceinline__ float4 loadRow16(const float4* p) {
-    const float4 v = *p;
-#if PTSS_ROW128
-    asm volatile("" ::"v"(v.w));
-#endif
-    return v;
-}
+// The tests use three of a row's four words, and hipcc narrows each fetch to ds_read_b96 — for these broadcast reads the
+// faster form (8.4 against 14 SIMD-cycles per wave-read for ds_read_b128, tools/microbench/loops.hip: the LDS-to-VGPR
+// return path moves bytes, and 768 are fewer than 1,024).
+__device__ __forceinline__ float4 loadRow16(const float4* p) { return *p; }
 __device__ __forceinline__ TriRows loadTri(const float4* tr) { return TriRows{loadRow16(tr), loadRow16(tr + 1), loadRow16(tr + 2)}; }
 // the camera-origin test (triangleTestPrimary) never looks at v0
 __device__ __forceinline__ TriRows loadTriEdges(const float4* tr) { return TriRows{float4{0, 0, 0, 0}, loadRow16(tr + 1), loadRow16(tr + 2)}; }
 
-#if PTSS_TRI_GUARD2  // A/B: the general reciprocal (two range compares)
-__device__ __forceinline__ float triRcp(float det) { return ptm::rcp(det); }
-#else
 __device__ __forceinline__ float triRcp(float det) { return ptm::rcp_if_above_1em7(det); }
-#endif
 
 // Lane predicates travel as 64-bit wave masks (one v_cmp each, combined with scalar ANDs, carried over the wave-uniform
 // branch in SGPRs, turned back into a lane predicate for free by inverse_ballot). As bools they made hipcc round-trip
@@ -245,7 +226,7 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     return h;
 }
 
-// ---- The closest hit's triangle loop, lean form (PTSS_TRI_STRAIGHT; triangleTest stays for the any-hit loops and as the
+// ---- The closest hit's triangle loop, lean form (triangleTest stays for the any-hit loops and as the
 // fallback). Same operations on the same values as triangleTest for every lane whose result is used; what changes:
 //   * The reciprocal's range guard moves out of the loop: |det| = |e1 . (d x e2)| <= |e1| |e2| |d| (1 + 4 ulp); the host
 //     bounds |e1| |e2| <= 2^100 (SceneLayout::triDetBounded) and the caller tests |d|^2 < 2^30 once per query, so
@@ -256,16 +237,16 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
 //     either way.
 //   * Only (distance, index, w1, w2) of the best hit travel through the loop, merged with selects (no exec-masked accept
 //     block); w0 = 1 - (w1 + w2) is recomputed from the kept pair by the caller — the same operation on the same values.
-//   * kExit = 2 keeps triangleTest's ONE wave-uniform exit (after the distance test): tiles of the early bounces are
-//     coherent — neighbouring pixels — and then whole waves do reject a triangle early. kExit = 1 (no exit at all) is the
-//     faster loop on incoherent rays (tools/microbench/loops.hip: 157 -> 138 SIMD-cycles per triangle per wave) and the
-//     slower kernel (same-box A/B: -1.6 %); A/B switch only.
+//   * triangleTest's ONE wave-uniform exit (after the distance test) stays: tiles of the early bounces are coherent —
+//     neighbouring pixels — and then whole waves do reject a triangle early. (No exit at all is the faster loop on
+//     incoherent rays, tools/microbench/loops.hip: 157 -> 138 SIMD-cycles per triangle per wave, and the slower kernel:
+//     same-box A/B -1.6 %.)
 struct TriBest {
     float dist;  // the running `distance` (Primitives.h:52), shared with the sphere phase
     int idx;     // -1: no triangle accepted
     float w1, w2;
 };
-template <bool kPrimary, bool kExit>
+template <bool kPrimary>
 __device__ __forceinline__ void triangleHybrid(const TriRows& tr, float4 ps, float4 pr, int i, vec3 o, vec3 d, unsigned long long liveMask,
                                                TriBest& best) {
     const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
@@ -285,7 +266,7 @@ __device__ __forceinline__ void triangleHybrid(const TriRows& tr, float4 ps, flo
     }
     const float dist = e2r * inverseDet;
     const unsigned long long passMask = liveMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > best.dist));
-    if (!kExit || passMask != 0ull) {
+    if (passMask != 0ull) {
         const float b1 = dot(s, q) * inverseDet;
         const float b2 = dot(d, r) * inverseDet;
         const float b0 = 1.0f - (b1 + b2);
@@ -304,11 +285,6 @@ __device__ __forceinline__ void triangleHybrid(const TriRows& tr, float4 ps, flo
 // primaryPrepKernel evaluates these once per camera with the very same operations; the per-lane work
 // that is left is identical to the generic tests (same values, same order), minus 8 of 15 / 12 of 55
 // instructions.
-__device__ __forceinline__ bool sphereMayHitPrimary(float4 pv /* v, c */, vec3 d) {
-    const float b = dot(d, xyz(pv)) * 2;
-    const float disc = (b * b) - 4 * pv.w;
-    return !(disc < 0);
-}
 
 __device__ __forceinline__ bool sphereTestPrimary(float4 pv, vec3 d, float limit, float& t) {
     const float b = dot(d, xyz(pv)) * 2;
@@ -357,7 +333,7 @@ __device__ __forceinline__ TriHit triangleTestPrimary(const TriRows& tr, float4 
 
 // ---- sphere candidate masks, CudaTracer.cu:127-133 / :438-444 through Primitives.h:107-118 -------------------------
 // bit j of the result = "sphere j of this block of up to 32 passes the reference's discriminant test" — the very
-// operations of sphereMayHit, four spheres per trip: the four rows are fetched with one address and immediate offsets
+// operations of the test above (Primitives.h:109-118), four spheres per trip: the four rows are fetched with one address and immediate offsets
 // (the host pads the sphere rows to a multiple of four, packScene; a padding row's bit is dropped by the caller's `keep`
 // mask), and each verdict enters the mask through the carry of one add (mask = 2 * mask + verdict: v_cmp + v_addc
 // instead of v_cmp + v_cndmask + v_or and a v_mov for the bit). That leaves the first sphere in the highest bit; one
@@ -378,7 +354,7 @@ __device__ __forceinline__ void shiftInMayHit(uint32_t& rev, float bb, float c4)
 // magnitude (a difference of two floats), so its sign decides both forms alike (c = 0: neither `<` holds). NaN or
 // infinite operands make both compares false. Pinned on adversarial operands by tests/test_sphere_forms.py.
 template <bool kBounded>
-__device__ __forceinline__ void shiftInSphere(uint32_t& rev, float4 sp, vec3 o, vec3 d) {  // sphereMayHit's operations
+__device__ __forceinline__ void shiftInSphere(uint32_t& rev, float4 sp, vec3 o, vec3 d) {  // Primitives.h:109-118
     const vec3 v = o - xyz(sp);
     if constexpr (kBounded) {
         const float h = dot(d, v);
@@ -391,7 +367,7 @@ __device__ __forceinline__ void shiftInSphere(uint32_t& rev, float4 sp, vec3 o, 
     }
 }
 template <bool kBounded>
-__device__ __forceinline__ void shiftInSpherePrimary(uint32_t& rev, float4 pv, vec3 d) {  // sphereMayHitPrimary's
+__device__ __forceinline__ void shiftInSpherePrimary(uint32_t& rev, float4 pv, vec3 d) {  // the same from the camera-origin precomputes
     if constexpr (kBounded) {
         const float h = dot(d, xyz(pv));
         shiftInMayHit(rev, h * h, pv.w);
@@ -446,23 +422,6 @@ __device__ __forceinline__ uint32_t sphereCandidatesStridedPairs(const float4* f
     return __builtin_bitreverse32(rev) >> (32 - 2 * trips);
 }
 __device__ __forceinline__ uint32_t lowBits(int cnt) { return (cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u); }
-// the same for a lane that visits every `stride`-th sphere starting at its own `first` row (anyHitSplit). Rows past the
-// scene's last sphere may be read (at most 31 of them: other rows of the scene image, which always ends in the 65-row
-// tone-map table); their bits are dropped by the caller.
-template <bool kBounded>
-__device__ __forceinline__ uint32_t sphereCandidatesStrided(const float4* first, int stride, int cnt, vec3 o, vec3 d) {
-    const int trips = (cnt + 3) >> 2;
-    uint32_t rev = 0;
-    for (int g = 0; g < trips; ++g) {
-        const float4* p = first + 4 * g * stride;
-        const float4 r0 = p[0], r1 = p[stride], r2 = p[2 * stride], r3 = p[3 * stride];
-        shiftInSphere<kBounded>(rev, r0, o, d);
-        shiftInSphere<kBounded>(rev, r1, o, d);
-        shiftInSphere<kBounded>(rev, r2, o, d);
-        shiftInSphere<kBounded>(rev, r3, o, d);
-    }
-    return __builtin_bitreverse32(rev) >> (32 - 4 * trips);
-}
 __device__ __forceinline__ uint32_t lowBitsClamped(int cnt) { return (cnt <= 0) ? 0u : lowBits(cnt); }
 
 // ---- closest hit over spheres then triangles, CudaTracer.cu:121-141 ---------------------------
@@ -471,21 +430,6 @@ __device__ __forceinline__ uint32_t lowBitsClamped(int cnt) { return (cnt <= 0) 
 // fails the discriminant test never changes `distance`, so visiting only the candidates, in the
 // same order, accepts exactly what the reference's full loop accepts — but the square-root path
 // runs a few times per lane instead of once per sphere for the whole wave.
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
-__device__ unsigned long long g_chist[8];
-#endif
-// diagnostic build only (-DPTSS_SHIST, tools/scatter_hist.py): how many waves execute each block of scatter(), and for how many lanes
-#ifdef PTSS_SHIST
-#define PTSS_SCOUNT(k, cond)                                                                   \
-    do {                                                                                       \
-        const unsigned long long _m = __ballot(cond);                                          \
-        if (_m != 0ull && __lane_id() == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) { \
-            atomicAdd(&g_chist[k], 1ull + ((unsigned long long)__popcll(_m) << 32));           \
-        }                                                                                      \
-    } while (0)
-#else
-#define PTSS_SCOUNT(k, cond) do {} while (0)
-#endif
 struct Hit {
     float distance;
     int kind, idx;  // kind: 0 none, 1 sphere, 2 triangle
@@ -534,6 +478,8 @@ __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec
     return unitDir ? ((__builtin_bitreverse32(rev) >> (32 - 4 * trips)) & all) : all;
 }
 
+#include "ptss_diag.h"
+
 // Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
 // from position (chunk mod kChunkSpheres) on, wrapping, so that the 16-byte gathers of a wave spread over the LDS banks;
 // verdicts enter through the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
@@ -575,33 +521,6 @@ __device__ __forceinline__ int popChunk(ChunkBits& b) {  // lowest set bit, remo
     return 32 * q + k;
 }
 
-__device__ __forceinline__ void closestSpheresChunked(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, Hit& h) {
-    const int* orig = reinterpret_cast<const int*>(cold + L.offSphereOrig);  // global memory (SceneLayout::ldsVec4)
-    const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
-    int bestOrig = -1;
-    for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
-        ChunkBits chunks = chunkBits128(sc, L, g0, o, d, unitDir, live);
-        while (anyChunk(chunks)) {
-            const int chunk = g0 + popChunk(chunks);
-            const int base = chunk * kChunkSpheres;
-            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, o, d);
-            while (mask != 0) {
-                const int j = chunkSlot(__builtin_ctz(mask), chunk);
-                mask &= mask - 1;
-                float t;
-                if (sphereTest(sc[L.offSphere + base + j], o, d, h.distance, t)) {  // t <= h.distance
-                    const int who = orig[base + j];
-                    if (t < h.distance || who > bestOrig) {
-                        h.distance = t;
-                        h.kind = 1;
-                        h.idx = base + j;
-                        bestOrig = who;
-                    }
-                }
-            }
-        }
-    }
-}
 
 __device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, bool live) {
     const bool unitDir = ptm::abs(dot(w_i, w_i) - 1.0f) <= kAccelDirEps;
@@ -627,7 +546,6 @@ __device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLa
     return occluded;
 }
 
-#if PTSS_REGROUP
 // ---- The same traversal with the work REGROUPED across the wave. In a dense scene an incoherent ray touches 30-50 chunks
 // and the counts differ widely between lanes: walking them lane by lane keeps 34 % of the lanes busy
 // (tools/stress_counters.sh). Here every lane publishes its ray and its chunk bits in the wave's LDS area, an exclusive
@@ -735,40 +653,7 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
         waveLdsFence();
     }
     const unsigned long long won = best[lane];
-#ifdef PTSS_CULLSTAT   // diagnostic (tools/cull_stat.py): of the chunks a ray's line touches, how many are NOT wholly beyond its final hit?
-    {
-        const float T = (won == ~0ull) ? ptm::inf() : asF((uint32_t)(won >> 32));
-        uint32_t touched = 0, needed = 0;
-        for (int g = 0; g < L.numChunks && g < 128; g += 32) {
-            const int left = L.numChunks - g;
-            const uint32_t bits = live ? chunkMask(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
-            uint32_t rev = 0;
-            const int trips = ((left < 32 ? left : 32) + 3) >> 2;
-            for (int q = 0; q < 4 * trips; ++q) {
-                const float4 b = sc[L.offChunk + g + q];
-                const vec3 v = o - xyz(b);
-                const float dv = dot(d, v), vv = dot(v, v), a = -dv - T;
-                const bool ahead = unitDir && (a > 0.0f) && ((a * a) * (1.0f - 2e-5f) > b.w + kAccelMu * vv);
-                rev |= ahead ? 0u : (1u << q);
-            }
-            touched += (uint32_t)__builtin_popcount(bits);
-            needed += (uint32_t)__builtin_popcount(bits & rev);
-        }
-        uint32_t st = 0, sn = 0, hits = 0;
-        for (uint32_t bit = 0; bit < 7; ++bit) {
-            st += (uint32_t)__popcll(__ballot((touched >> bit) & 1u)) << bit;
-            sn += (uint32_t)__popcll(__ballot((needed >> bit) & 1u)) << bit;
-        }
-        hits = (uint32_t)__popcll(__ballot(live && won != ~0ull));
-        const uint32_t rays = (uint32_t)__popcll(__ballot(live));
-        if (lane == 0) {
-            atomicAdd(&g_chist[0], (unsigned long long)st);
-            atomicAdd(&g_chist[1], (unsigned long long)sn);
-            atomicAdd(&g_chist[2], (unsigned long long)rays);
-            atomicAdd(&g_chist[3], (unsigned long long)hits);
-        }
-    }
-#endif
+    PTSS_DIAG_CULL(sc, L, o, d, unitDir, live, won);
     if (live && won != ~0ull) {
         const int pos = posOf[0xffffffffu - (uint32_t)won];
         float t;
@@ -779,20 +664,16 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
     }
     waveLdsFence();
 }
-#endif
 
-#if PTSS_REGROUP_SHADOW
 // ---- Shadow rays of a dense queue pass, hybrid: a blocked segment is usually blocked within its first chunks, so every
 // lane walks up to kWarmChunks of its own chunks first (cheap early exits); what is left belongs to the long walkers —
 // the segments that reach their light have to visit all 30-50 chunks — and is regrouped across the wave like the closest
 // hit's work (closestSpheresRegrouped), the merge being "set the owner's blocked flag". The tables live in the half of
 // the wave's queue planes that the current pass does not read (tab[plane] = that half of plane `plane`), which is why
 // the caller uses this only for a pass whose other half is free.
-#ifndef PTSS_WARM
-#define PTSS_WARM 2   // chunks of 16 in kd order (round 2), configs[5] scene at S = 4, same box: 0: 4,571, 1: 4,589, 2: 4,597-4,605,
-                      // 3: 4,585, 4: 4,535, 8: 4,270, 16: 4,189 Mrays/s (round 1, chunks of 8 in Morton order: 2 ... 16 within 2 %)
-#endif
-constexpr int kWarmChunks = PTSS_WARM;
+// chunks of 16 in kd order, configs[4]'s scene at S = 4, same box: 0: 4,571, 1: 4,589, 2: 4,597-4,605, 3: 4,585, 4: 4,535,
+// 8: 4,270, 16: 4,189 Mrays/s
+constexpr int kWarmChunks = 2;
 
 __device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLayout& L, const float* seg, float* tab, vec3 lo,
                                                  vec3 w_i, float distance, bool have) {
@@ -906,7 +787,6 @@ __device__ __forceinline__ bool anyTriangles(const float4* sc, const SceneLayout
     }
     return __builtin_amdgcn_inverse_ballot_w64(hitMask);
 }
-#endif
 
 template <bool kPrimary, bool kAccel, bool kBounded>
 __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
@@ -915,43 +795,12 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
     h.kind = 0;
     h.idx = 0;
     h.w0 = h.w1 = h.w2 = 0;
-#if PTSS_REGROUP
     if constexpr (kAccel) closestSpheresRegrouped(sc, cold, L, o, d, live, h, ws);
-#else
-    if constexpr (kAccel) closestSpheresChunked(sc, cold, L, o, d, live, h);
-#endif
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
-#if PTSS_SPHERE_UNROLL & 1
         uint32_t mask = sphereCandidates<kPrimary, kBounded>(sc + (kPrimary ? L.offPrimSphere : L.offSphere) + base, cnt, o, d);
         mask &= live ? lowBits(cnt) : 0u;
-#else
-        uint32_t mask = 0;
-        for (int j = 0; j < cnt; ++j) {
-            const bool may = kPrimary ? sphereMayHitPrimary(sc[L.offPrimSphere + base + j], d)
-                                      : sphereMayHit(sc[L.offSphere + base + j], o, d);
-            if (may) mask |= 1u << j;
-        }
-        if (!live) mask = 0;
-#endif
-#ifdef PTSS_CHIST  // diagnostic: sphere candidates per lane, wave maximum vs wave mean (tools/candidate_hist.py)
-        {
-            const uint32_t pc = (uint32_t)__builtin_popcount(mask);
-            uint32_t mx = 0;
-            while (__any(pc > mx)) ++mx;
-            uint32_t total = 0;
-            for (uint32_t b = 0; b < 6; ++b) total += (uint32_t)__popcll(__ballot((pc >> b) & 1u)) << b;
-            if (__lane_id() == 0) {
-                atomicAdd(&g_chist[0], (unsigned long long)mx);
-                atomicAdd(&g_chist[1], (unsigned long long)total);
-                atomicAdd(&g_chist[2], 1ull);
-                atomicAdd(&g_chist[3], (unsigned long long)__popcll(__ballot(live)));
-            }
-        }
-#endif
-#if PTSS_ABLATE & 16   // timing only: at most two candidates per lane (what perfect balancing of the candidate loop could save)
-        mask = (mask & -mask) | ((mask & (mask - 1)) & -(mask & (mask - 1)));
-#endif
+        PTSS_DIAG_CANDIDATES(mask, live, 0);
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -966,7 +815,6 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
         }
     }
     const unsigned long long liveMask = maskOf(live);
-#if PTSS_TRI_STRAIGHT
     // one test per query instead of one per triangle: |d|^2 < 2^30 in every lane (false for a NaN direction)
     if (L.triDetBounded && waveAll(dot(d, d) < 0x1p30f)) {
         TriBest best{h.distance, -1, 0.0f, 0.0f};
@@ -977,7 +825,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
                 ps = sc[L.offPrimTri + 2 * i];
                 pr = loadRow16(sc + L.offPrimTri + 2 * i + 1);
             }
-            triangleHybrid<kPrimary, PTSS_TRI_STRAIGHT == 2>(tcur, ps, pr, i, o, d, liveMask, best);
+            triangleHybrid<kPrimary>(tcur, ps, pr, i, o, d, liveMask, best);
         }
         if (best.idx >= 0) {
             h.distance = best.dist;
@@ -989,8 +837,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
         }
         return h;
     }
-#endif
-    for (int i = 0; i < L.numTriangles; ++i) {
+    for (int i = 0; i < L.numTriangles; ++i) {   // the guarded loop: unbounded edges, or a direction of enormous length
         const TriRows tcur = kPrimary ? loadTriEdges(sc + L.offTri + 3 * i) : loadTri(sc + L.offTri + 3 * i);
         const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], loadRow16(sc + L.offPrimTri + 2 * i + 1), d,
                                                          h.distance, liveMask)
@@ -1017,36 +864,9 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
     if constexpr (kAccel) occluded = anySphereChunked(sc, L, lo, w_i, distance, live);
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
-#if PTSS_SPHERE_UNROLL & 8
         uint32_t mask = sphereCandidatesPairs<kBounded>(sc + L.offSphere + base, cnt, lo, w_i);
         mask &= (live && !occluded) ? lowBits(cnt) : 0u;
-#elif PTSS_SPHERE_UNROLL & 2
-        uint32_t mask = sphereCandidates<false, kBounded>(sc + L.offSphere + base, cnt, lo, w_i);
-        mask &= (live && !occluded) ? lowBits(cnt) : 0u;
-#else
-        uint32_t mask = 0;
-        for (int j = 0; j < cnt; ++j)
-            if (sphereMayHit(sc[L.offSphere + base + j], lo, w_i)) mask |= 1u << j;
-        if (!live || occluded) mask = 0;
-#endif
-#ifdef PTSS_CHIST
-        {
-            const uint32_t pc = (uint32_t)__builtin_popcount(mask);
-            uint32_t mx = 0;
-            while (__any(pc > mx)) ++mx;
-            uint32_t total = 0;
-            for (uint32_t b = 0; b < 6; ++b) total += (uint32_t)__popcll(__ballot((pc >> b) & 1u)) << b;
-            if (__lane_id() == 0) {
-                atomicAdd(&g_chist[4], (unsigned long long)mx);
-                atomicAdd(&g_chist[5], (unsigned long long)total);
-                atomicAdd(&g_chist[6], 1ull);
-                atomicAdd(&g_chist[7], (unsigned long long)__popcll(__ballot(live)));
-            }
-        }
-#endif
-#if PTSS_ABLATE & 16
-        mask = (mask & -mask) | ((mask & (mask - 1)) & -(mask & (mask - 1)));
-#endif
+        PTSS_DIAG_CANDIDATES(mask, live, 4);
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -1082,22 +902,9 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
     const int sphereSteps = (L.numSpheres + g - 1) >> shift;
     for (int base = 0; base < sphereSteps; base += 32) {
         const int cnt = (sphereSteps - base < 32) ? (sphereSteps - base) : 32;
-#if PTSS_SPHERE_UNROLL & 16
         uint32_t mask = sphereCandidatesStridedPairs<kBounded>(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
-        mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
-#elif PTSS_SPHERE_UNROLL & 4
-        uint32_t mask = sphereCandidatesStrided<kBounded>(sc + L.offSphere + (base << shift) + sub, g, cnt, lo, w_i);
         // this lane's spheres are sub, sub + g, ...: step j exists for it iff (j << shift) + sub < numSpheres
         mask &= (live && !occluded) ? lowBitsClamped(((L.numSpheres - sub + g - 1) >> shift) - base) : 0u;
-#else
-        uint32_t mask = 0;
-        for (int j = 0; j < cnt; ++j) {
-            const int idx = ((base + j) << shift) + sub;
-            const bool in = idx < L.numSpheres;
-            if (in && sphereMayHit(sc[L.offSphere + (in ? idx : 0)], lo, w_i)) mask |= 1u << j;
-        }
-        if (!live || occluded) mask = 0;
-#endif
         while (mask != 0) {
             const int j = __builtin_ctz(mask);
             mask &= mask - 1;
@@ -1123,7 +930,6 @@ __device__ __forceinline__ bool anyHitSplit(const float4* sc, const SceneLayout&
     return occluded || __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
-#if PTSS_NEE_PAIRS
 // ---- lineOfSight for the TWO segments a surface point sends to the two lights of an NEE round. They share their origin,
 // and so everything the tests compute from origin and primitive alone: a sphere's v = o - centre and c = |v|^2 - r^2
 // (7 of its 13 / 15 instructions), a triangle's s = o - v0, r = s x e1 and e2 . r (12 of the ~32 up to the distance test).
@@ -1228,7 +1034,6 @@ __device__ __forceinline__ void pairAnyHit(const float4* sc, const SceneLayout& 
     occA = occA || __builtin_amdgcn_inverse_ballot_w64(blockedA);
     occB = occB || __builtin_amdgcn_inverse_ballot_w64(blockedB);
 }
-#endif
 
 // one light's Lambert term, CudaTracer.cu:360-366 / :379-385
 __device__ __forceinline__ void addLambertTerm(vec3& radiance, float cosI, vec3 power, float distance2,
@@ -1263,7 +1068,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
     const int flags = (int)asU(mMisc.z);
 
     float r = ptrng::uniform(ray.rng);
-    PTSS_SCOUNT(0, true);  // waves (and lanes) in scatter at all
+    PTSS_DIAG_SCATTER(0, true);  // waves (and lanes) in scatter at all
 
     int kind = kLobeNone;
     bool decided = false;
@@ -1281,7 +1086,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         }
     }
 
-    PTSS_SCOUNT(1, !decided);  // the non-Lambert block
+    PTSS_DIAG_SCATTER(1, !decided);  // the non-Lambert block
     if (!decided) {
         // computeSinT2AndRefractiveIndexes :474-494 (flips cosI when inside)
         float n1, n2;
@@ -1293,7 +1098,6 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
             n1 = mMisc.y;
             n2 = 1.0f;
         }
-#if PTSS_FRESNEL_SKIP
         // The Snell / Fresnel terms (two square roots' worth and three divisions) feed only the Fresnel-weighted specular
         // lobe (:248-249) and the refraction lobe (:300-311). A material with the pure-reflection bit (mirrors AND every
         // Cook-Torrance material, 0x03 & 0x01) and no refraction never reads them: its lanes skip the block, and a wave
@@ -1301,20 +1105,12 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         const bool readsFresnel = (mSpecular.w > 0.0f && !(flags & PTSS_MAT_FLAG_PURE_REFLECTION)) || refrAvg > 0.0f;
         float n = 0.0f, sinT2 = 0.0f;
         float fresnelReflective = 1.0f;
-        PTSS_SCOUNT(2, readsFresnel);  // Snell / Fresnel terms
+        PTSS_DIAG_SCATTER(2, readsFresnel);  // Snell / Fresnel terms
         if (readsFresnel) {
-            n = ptm::div(n1, n2);
+            n = ptm::div(n1, n2);    // computeSinT2AndRefractiveIndexes :491-493
             sinT2 = n * n * (1.0f - cosI * cosI);
         }
-        if (readsFresnel && !(sinT2 > 1.0f)) {
-#else
-        const float n = ptm::div(n1, n2);
-        const float sinT2 = n * n * (1.0f - cosI * cosI);
-
-        // computeFresnelForReflectance :457-472
-        float fresnelReflective = 1.0f;
-        if (!(sinT2 > 1.0f)) {
-#endif
+        if (readsFresnel && !(sinT2 > 1.0f)) {   // computeFresnelForReflectance :457-472
             const float cosT = ptm::sqrt(1.0f - sinT2);
             const float r_s = ptm::div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
             const float r_p = ptm::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
@@ -1347,7 +1143,7 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         if (!decided && refrAvg > 0.0f) {
             const float fresnelRefractive = 1.0f - fresnelReflective;
             r -= refrAvg * fresnelRefractive;
-            PTSS_SCOUNT(3, r < 0.0f);  // refraction lobe
+            PTSS_DIAG_SCATTER(3, r < 0.0f);  // refraction lobe
             if (r < 0.0f) {
                 // refrRay :516-531
                 decided = true;
@@ -1363,10 +1159,10 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
         if (!decided) ray.active = false;  // absorbed, :316-317
     }
 
-    PTSS_SCOUNT(4, kind != kLobeNone);       // the shared sampler tail
-    PTSS_SCOUNT(5, kind == kLobeBeckmann);   // ... with the Beckmann elevation (atan, log) and the Cook-Torrance weight
-    PTSS_SCOUNT(6, kind == kLobePhong);      // ... with the Phong elevation (pow)
-    PTSS_SCOUNT(7, kind == kLobeLambert);
+    PTSS_DIAG_SCATTER(4, kind != kLobeNone);       // the shared sampler tail
+    PTSS_DIAG_SCATTER(5, kind == kLobeBeckmann);   // ... with the Beckmann elevation (atan, log) and the Cook-Torrance weight
+    PTSS_DIAG_SCATTER(6, kind == kLobePhong);      // ... with the Phong elevation (pow)
+    PTSS_DIAG_SCATTER(7, kind == kLobeLambert);
     if (kind != kLobeNone) {  // one copy of the sampler for every kind
         const float u1 = ptrng::uniform(ray.rng);
         const float u2 = ptrng::uniform(ray.rng);
@@ -1405,16 +1201,10 @@ __device__ __forceinline__ vec3 scatter(const float4* mat, RayRegs& ray, vec3 po
     return result;
 }
 
-// one channel of writeToPixelsKernel, CudaTracer.cu:72-85: clamp, gamma 1/2.2, scale to 8 bits. PTSS_QUANT_TABLE = 1
-// takes the proven-equal table form (ptquant.h): a hardware log2/exp2 guess settled by two exact threshold compares,
-// ~12 instructions instead of the ~90 of the software pow — three of these run for every wave that ends a path.
-__device__ __forceinline__ uint32_t quantizeSample(float radiance, const float* T) {
-#if PTSS_QUANT_TABLE
-    return ptq::quantize_fast(radiance, T);
-#else
-    return ptq::quantize_literal(radiance);
-#endif
-}
+// one channel of writeToPixelsKernel, CudaTracer.cu:72-85: clamp, gamma 1/2.2, scale to 8 bits — in the proven-equal table
+// form (ptquant.h): a hardware log2/exp2 guess settled by two exact threshold compares, ~12 instructions instead of the ~90
+// of the software pow; three of these run for every wave that ends a path.
+__device__ __forceinline__ uint32_t quantizeSample(float radiance, const float* T) { return ptq::quantize_fast(radiance, T); }
 
 // The per-pixel home record of the random stream: 8 words (v0..v4, d, 2 pad) = one 32-byte sector, so
 // parking or fetching a stream is two 16-byte accesses instead of six scattered 4-byte ones.
@@ -1469,27 +1259,6 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
     }
     storeHome(fb.rngHome, stream, r.rng);
 }
-
-// ---- diagnostic build only (-DPTSS_STAMPS): per-phase wave-cycle accounting. The shipped kernel executes no stamp.
-#ifdef PTSS_STAMPS
-#define PTSS_STAMP_INIT() unsigned long long _st_prev = clock64(), _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define PTSS_STAMP(k)                                             \
-    do {                                                          \
-        __builtin_amdgcn_s_waitcnt(0);                            \
-        const unsigned long long _t = clock64();                  \
-        _st_acc[k] += _t - _st_prev;                              \
-        _st_prev = _t;                                            \
-    } while (0)
-#define PTSS_STAMP_FLUSH()                                                        \
-    do {                                                                          \
-        if (lane == 0)                                                            \
-            for (int _k = 0; _k < 8; ++_k) atomicAdd(&fb.stamps[_k], _st_acc[_k]); \
-    } while (0)
-#else
-#define PTSS_STAMP_INIT() do {} while (0)
-#define PTSS_STAMP(k) do {} while (0)
-#define PTSS_STAMP_FLUSH() do {} while (0)
-#endif
 
 // ---- the loop guard with frame lanes (FrameBuffers, "frame lanes"): the frame's live count of bounce b >= 1 when this
 // lane's own count `own` is not above the threshold. Waits (bounded) until every workgroup of each peer's bounce b - 1 has
@@ -1617,7 +1386,7 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // kSceneInLds = true : the scene blob is staged into LDS once per workgroup and read by broadcast
 //                      (ds_read, same address in every lane; per-lane gathers in the candidate loops).
 // kSceneInLds = false: the blob is read in place (scalar loads where the address is wave-uniform);
-//                      A/B switch only (PTSS_SCENE_PATH=scalar).
+//                      scenes whose image does not fit the 64 KiB dynamic-LDS window take this path.
 //
 // One tile = kBlock rays = one workgroup pass:
 //   1. load ray, closest hit (sphere candidate masks + uniform triangle loop), surfel, emission;
@@ -1645,7 +1414,7 @@ template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded,
 __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
                                            const TileMap& tile, const EyeParams& eye) {
     extern __shared__ float4 lds[];
-    constexpr bool kPairs = PTSS_NEE_PAIRS && kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
+    constexpr bool kPairs = kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
     if constexpr (kFirst) {
@@ -1662,7 +1431,6 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     float4* work = lds + (kSceneInLds ? L.ldsVec4 : 0);
-    [[maybe_unused]] uint32_t* scratch = reinterpret_cast<uint32_t*>(work);  // PTSS_WAVE_COMPACT=0 variant only
     float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
     uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
     unsigned char* wqAnswer = reinterpret_cast<unsigned char*>(wqOwner + kQueueCap);  // [kNeeLights][64], 0 / 1
@@ -1700,7 +1468,6 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
         }
 
         // ---- 1. closest hit + surfel (pathTraceKernel :121-163) -----------------------------------
-        PTSS_STAMP_INIT();
         RayRegs ray;
         ray.o = ray.d = ray.L0 = ray.T = v3(0, 0, 0);
         ray.pix = 0;
@@ -1723,13 +1490,10 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 ray.active = true;
             }
         } else {
-#if PTSS_DEFER_LOADS
+            // a ray's planes are fetched where the tile first needs them (origin/direction here, the RNG state before the light
+            // samples, radiance/throughput/pixel before the update): 13 fewer live registers across the closest-hit loops
             if (valid) loadRayGeometry(tileBlock(in, base), threadIdx.x, ray);
-#else
-            if (valid) loadRay(tileBlock(in, base), threadIdx.x, ray);
-#endif
         }
-        PTSS_STAMP(0);  // ray load / eye-ray generation
 #if PTSS_ABLATE & 2
         Hit h;
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
@@ -1737,13 +1501,10 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
 #else
         const Hit h = closestHit<kFirst && !kAccel, kAccel, kBounded>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
 #endif
-        PTSS_STAMP(1);  // closest hit
         const bool hit = valid && h.kind != 0;
-#if PTSS_DEFER_LOADS
         if constexpr (!kFirst) {
             if (valid) loadRayRng(tileBlock(in, base), threadIdx.x, ray);
         }
-#endif
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
         float cosI = 0;
         int materialIdx = 0;
@@ -1769,7 +1530,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
             uint32_t queued = 0;  // wave-uniform
             bool need[kNeeLights];
             float cosL[kNeeLights], distance2[kNeeLights];
-            [[maybe_unused]] vec3 pairW[kNeeLights];      // PTSS_NEE_PAIRS: the round's segments stay in registers until both are known
+            [[maybe_unused]] vec3 pairW[kNeeLights];      // kPairs: the round's segments stay in registers until both are known
             [[maybe_unused]] float pairReach[kNeeLights];
 #pragma unroll
             for (int k = 0; k < kNeeLights; ++k) {
@@ -1831,23 +1592,9 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 }
                 queued += (uint32_t)__popcll(m);
             }
-#ifdef PTSS_PAIRSTAT   // diagnostic (tools/pair_stat.py; built together with PTSS_CULLSTAT for the counters' plumbing)
-            {
-                const unsigned long long mb = __ballot(need[0] && need[1]), mo = __ballot(need[0] != need[1]), ml = __ballot(lit);
-                if (lane == 0) {
-                    atomicAdd(&g_chist[4], (unsigned long long)__popcll(mb));
-                    atomicAdd(&g_chist[5], (unsigned long long)__popcll(mo));
-                    atomicAdd(&g_chist[6], (unsigned long long)__popcll(ml));
-                    atomicAdd(&g_chist[7], 1ull);
-                }
-            }
-#endif
+            PTSS_DIAG_PAIRS(need[0], need[1], lit);
             waveLdsFence();
-#ifdef PTSS_QHIST  // diagnostic: histogram of the wave's queue length per NEE round (tools/queue_hist.py)
-            if (lane == 0) atomicAdd(&fb.stamps[queued == 0 ? 0 : (queued <= 8 ? 1 : (queued <= 16 ? 2 : (queued <= 32 ? 3 : (queued <= 64 ? 4 : (queued <= 72 ? 5 : (queued <= 96 ? 6 : 7))))))], 1ull);
-#endif
-            PTSS_STAMP(2);  // surfel + light sampling + enqueue
-#if PTSS_NEE_PAIRS
+            PTSS_DIAG_QUEUE(queued);
             if constexpr (kPairs) {
                 // One entry per lane that needs either segment: origin, the two directions and reaches, owner lane | need bits << 8
                 // (12 planes of 64). A pass is sized by what it holds: 49+ entries one lane each, fewer -> 32 / 16 / 8 entries
@@ -1903,10 +1650,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                     }
                     e0 += 1u << chunkLog;
                 }
-            } else
-#endif
-            {
-#if PTSS_SPLIT_SPARSE
+            } else {
             // Passes over the wave's queue, each sized by what is left (wave-uniform): 49+ segments -> a dense pass,
             // one lane per segment (anyHit, broadcast rows); fewer -> a chunk of 32 / 16 / 8 segments with 2 / 4 / 8
             // lanes per segment sharing the primitive list (anyHitSplit), so that a pass costs about what it holds:
@@ -1924,7 +1668,6 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
                 const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
                 const float reach = wq[6 * kQueueCap + es];
-#if PTSS_REGROUP_SHADOW
                 bool occ;
                 if (kAccel && (e0 != 0u || queued <= 64u)) {  // dense pass whose OTHER half of the queue planes is free
                     occ = anySpheresHybrid(sc, L, wq + e0, wq + (e0 == 0u ? 64 : 0), lo, wi, reach, have);
@@ -1932,9 +1675,6 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 } else {
                     occ = (shift == 0) ? anyHit<kAccel, kBounded>(sc, L, lo, wi, reach, have) : anyHitSplit<kBounded>(sc, L, lo, wi, reach, have, shift, (int)sub);
                 }
-#else
-                const bool occ = (shift == 0) ? anyHit<kAccel, kBounded>(sc, L, lo, wi, reach, have) : anyHitSplit<kBounded>(sc, L, lo, wi, reach, have, shift, (int)sub);
-#endif
                 const unsigned long long verdicts = __ballot(occ);  // all lanes vote before anyone branches
                 const unsigned long long group = ((1ull << (1u << shift)) - 1ull) << (mine << shift);
                 if (have && sub == 0u && (verdicts & group) != 0ull) {
@@ -1943,23 +1683,8 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 }
                 e0 += 1u << chunkLog;
             }
-#else
-            for (uint32_t e0 = 0; e0 < queued; e0 += 64) {  // dense passes over the wave's queue
-                const uint32_t e = e0 + lane;
-                const bool have = e < queued;
-                const uint32_t es = have ? e : 0u;
-                const vec3 lo = v3(wq[0 * kQueueCap + es], wq[1 * kQueueCap + es], wq[2 * kQueueCap + es]);
-                const vec3 wi = v3(wq[3 * kQueueCap + es], wq[4 * kQueueCap + es], wq[5 * kQueueCap + es]);
-                const bool occ = anyHit<kAccel, kBounded>(sc, L, lo, wi, wq[6 * kQueueCap + es], have);
-                if (have && occ) {
-                    const uint32_t ow = wqOwner[es];
-                    wqAnswer[(ow >> 8) * 64 + (ow & 63u)] = 1;
-                }
-            }
-#endif
             }
             waveLdsFence();
-            PTSS_STAMP(3);  // dense shadow passes
 #pragma unroll
             for (int k = 0; k < kNeeLights; ++k) {
                 const int li = l0 + k;
@@ -1975,18 +1700,9 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
 
         // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
         bool alive = false;
-        [[maybe_unused]] uint32_t classOfScatter = 3;   // PTSS_CLASS_RANK = 1: 0 diffuse material, 1 mirror-like, 2 refractive, 3 other
-#if PTSS_CLASS_RANK == 1
-        if (hit) {
-            const float4 m0 = mat[0], m1 = mat[1];
-            classOfScatter = (mat[2].w > 0.0f) ? 2u : ((m1.w > 0.0f) ? 1u : ((m0.w > 0.0f) ? 0u : 3u));
-        }
-#endif
-#if PTSS_DEFER_LOADS
         if constexpr (!kFirst) {
             if (valid) loadRayRadiance(tileBlock(in, base), threadIdx.x, ray);
         }
-#endif
         if (valid) {
             if (hit) {
                 // emmitance, :163 — read here, after the shadow passes, instead of being held in registers across them
@@ -2008,15 +1724,11 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
             }
             alive = ray.active && !kLast;
         }
-        PTSS_STAMP(4);  // lambert terms + scatter + radiance update
 
         // ---- 4+5. stream compaction of the survivors (replaces thrust::partition, :629) and
-        // writeToPixelsKernel for the paths that ended. PTSS_WAVE_COMPACT: each wave compacts on its
-        // own — 64-bit ballot, popcount lane rank, ONE returning atomic per wave on the shard's counter
-        // (16 counters share the load) — no barrier; the atomic is issued first so that its round trip
-        // hides behind the tone-mapping of the finished lanes. Otherwise: wave totals combined through
-        // LDS and one atomic per workgroup.
-#if PTSS_WAVE_COMPACT
+        // writeToPixelsKernel for the paths that ended. Each wave compacts on its own — 64-bit ballot, popcount lane rank, ONE
+        // returning atomic per wave on the shard's counter (16 counters share the load) — no barrier; the atomic is issued
+        // first so that its round trip hides behind the tone-mapping of the finished lanes.
         uint32_t slot = 0;
         if constexpr (!kLast) {
             const unsigned long long live = __ballot(alive);
@@ -2027,31 +1739,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                     base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], (uint32_t)__popcll(live));
                 slot = base0;  // consumed after the finish work below
                 if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
-#if PTSS_CLASS_RANK   // experiment ("material-class ray sorting"): survivors leave the wave ordered by class
-                // first, lane second — class = the lobe the ray just left through (PTSS_CLASS_RANK = 1: diffuse / mirror-like /
-                // refracted / other, from the throughput factor's origin) or the octant of its new direction (= 2). Legal:
-                // the random stream travels with the ray, so the image does not depend on slot order (parity tests unchanged).
-                {
-                    const unsigned long long below = (1ull << lane) - 1ull;
-#if PTSS_CLASS_RANK == 2
-                    const uint32_t cls = (ray.d.x < 0 ? 1u : 0u) | (ray.d.y < 0 ? 2u : 0u) | (ray.d.z < 0 ? 4u : 0u);
-                    constexpr uint32_t kClasses = 8;
-#else
-                    const uint32_t cls = classOfScatter;
-                    constexpr uint32_t kClasses = 4;
-#endif
-                    uint32_t rank = 0, before = 0;
-#pragma unroll
-                    for (uint32_t c = 0; c < kClasses; ++c) {
-                        const unsigned long long m = __ballot(alive && cls == c);
-                        rank = (cls == c) ? before + (uint32_t)__popcll(m & below) : rank;
-                        before += (uint32_t)__popcll(m);
-                    }
-                    slot = __shfl(slot, leader) + rank;
-                }
-#else
                 slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
-#endif
                 if (alive) storeRay(out, slot, ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
                 finishPath(fb, ray, quantT);
@@ -2059,29 +1747,6 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
         } else {
             if (valid && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
         }
-        PTSS_STAMP(5);
-#else
-        if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
-        PTSS_STAMP(5);  // finish (tone map, accumulate, park RNG)
-        if constexpr (!kLast) {
-            const unsigned long long live = __ballot(alive);
-            const uint32_t rank = __popcll(live & ((1ull << lane) - 1ull));
-            if (lane == 0) scratch[wave] = (uint32_t)__popcll(live);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t total = 0;
-                for (int w = 0; w < kWaves; ++w) total += scratch[w];
-                scratch[8] = total ? atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], total) : 0u;
-            }
-            __syncthreads();
-            uint32_t slot = scratch[8] + rank;
-            for (uint32_t w = 0; w < wave; ++w) slot += scratch[w];
-            if (alive) storeRay(out, slot, ray);
-            __syncthreads();  // scratch is rewritten by the next tile
-        }
-#endif
-        PTSS_STAMP(6);  // compaction (barriers, atomic, survivor stores)
-        PTSS_STAMP_FLUSH();
     }
 }
 
@@ -2244,8 +1909,8 @@ static hipError_t launchBounceT(hipStream_t st, const FrameBuffers& fb, const fl
     return hipGetLastError();
 }
 
-#if defined(PTSS_CHIST) || defined(PTSS_SHIST) || defined(PTSS_CULLSTAT)
-hipError_t readCandidateHist(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chist), 64); }
+#if PTSS_DIAG
+hipError_t readDiagCounters(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), 64); }
 #endif
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds) {
     return ((sceneInLds ? (size_t)layout.ldsVec4 : 0) + kBlockLdsVec4) * sizeof(float4);

@@ -120,9 +120,10 @@ int ptss_frame_lanes(const ptss_context* ctx, int* out);
  * process; a non-zero value means the loop guard of that frame was decided without the peer. */
 int ptss_guard_timeouts(ptss_context* ctx, unsigned int* out);
 
-/* Diagnostic builds only (-DPTSS_STAMPS, tools/build_variants.py "stamps"): wave-cycles spent per kernel
- * phase, summed over all waves since creation; all zero in the shipped library. */
-int ptss_debug_phase_cycles(ptss_context* ctx, unsigned long long* out8);
+/* Diagnostic builds only (-DPTSS_DIAG=<bits>, csrc/ptss_diag.h, tools/build_variants.py): the eight counter words of that
+ * build (sphere candidates per lane, scatter blocks, chunk culling, shadow-segment pairs, queue lengths); all zero in the
+ * shipped library, which carries no counter. */
+int ptss_debug_counters(ptss_context* ctx, unsigned long long* out8);
 
 const char* ptss_error_string(int code);
 const char* ptss_last_error_detail(void);

@@ -13,9 +13,9 @@ for _ in range(4):
     r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()
-L.ptss_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.ptss_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 8)()
-assert L.ptss_debug_phase_cycles(r._ctx, out) == 0
+assert L.ptss_debug_counters(r._ctx, out) == 0
 for name, o in (("closest hit", 0), ("any hit", 4)):
     mx, total, n, live = out[o], out[o + 1], out[o + 2], out[o + 3]
     print("%-12s chunks %10d  live lanes/wave %5.1f  candidates: wave max %.2f, mean per lane %.2f (per live lane %.2f) -> %.0f %% of the candidate loop is idle lanes"

@@ -14,9 +14,9 @@ r = ptss.Renderer(ptss.Scene("stress"), 1920, 1080, max_iterations=bounces, sync
 r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()
-L.ptss_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.ptss_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 8)()
-assert L.ptss_debug_phase_cycles(r._ctx, out) == 0
+assert L.ptss_debug_counters(r._ctx, out) == 0
 touched, needed, rays, hits = out[0], out[1], out[2], out[3]
 print("%d bounces: rays %d, sphere hits %.1f %%, chunks touched per ray %.2f, not beyond the final hit %.2f (%.0f %%)"
       % (bounces, rays, 100.0 * hits / rays, touched / rays, needed / rays, 100.0 * needed / max(touched, 1)))

@@ -15,9 +15,9 @@ for _ in range(2):
     r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()
-L.ptss_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.ptss_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 8)()
-assert L.ptss_debug_phase_cycles(r._ctx, out) == 0
+assert L.ptss_debug_counters(r._ctx, out) == 0
 both, one, lit, rounds = out[4], out[5], out[6], out[7]
 print("%s: per wave and round: lit lanes %.1f, both segments %.1f, one segment %.1f (%.0f %% of the lanes that queue anything)"
       % (preset, lit / rounds, both / rounds, one / rounds, 100.0 * one / max(both + one, 1)))

@@ -14,9 +14,9 @@ for _ in range(6):
     r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()
-L.ptss_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.ptss_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 8)()
-assert L.ptss_debug_phase_cycles(r._ctx, out) == 0
+assert L.ptss_debug_counters(r._ctx, out) == 0
 names = ["0", "1-8", "9-16", "17-32", "33-64", "65-72", "73-96", "97-128"]
 passes_now = [0, 1, 1, 1, 1, 2, 2, 2]
 # split passes: q <= 32 gets g = 64 / pow2ceil(q) lanes per entry; a second pass holds q - 64 entries

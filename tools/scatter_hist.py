@@ -14,9 +14,9 @@ for _ in range(4):
     r.generate_frame()
 r.synchronize()
 L = ptss.device_lib()
-L.ptss_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.ptss_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 8)()
-assert L.ptss_debug_phase_cycles(r._ctx, out) == 0
+assert L.ptss_debug_counters(r._ctx, out) == 0
 names = ["scatter at all", "non-Lambert block (Snell, specular, refraction)", "Snell / Fresnel terms", "refraction lobe", "sampler tail (2 draws, sincos, rotation)",
          "... Beckmann elevation + Cook-Torrance weight", "... Phong elevation (pow)", "... Lambert elevation (sqrt)"]
 waves0 = out[0] & 0xffffffff
