@@ -4,17 +4,19 @@
   python bench.py [--config c3] --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path = one call of the generateFrame drop-in (reference
+A "step" is P passes of the hot path; a pass = one call of the generateFrame drop-in (reference
 CudaTracer.cu:587-647): eye rays -> up to B x [intersect + NEE + scatter + compaction] -> accumulate,
-for S = --samples-per-pass independent samples per pixel (cfg.samplesPerPass; S = 1 is the reference's one
-sample per tick). Workloads (`--config`, BASELINE.json `configs`):
+for S independent samples per pixel (cfg.samplesPerPass; S = 1 is the reference's one sample per tick). The K timed steps
+together render the configuration's spp: K x P x S = spp (`plan_steps`; with the defaults P = 1). Workloads (`--config`,
+BASELINE.json `configs`):
 
   c3 (default)  configs[2]/[3]: 1920x1080, preset "mixed" (22 spheres + 16 triangles, Lambert / Phong / Cook-Torrance /
-                glass / mirror), 8 bounces; default S = 40 x 50 passes = the config's 2000 spp
+                glass / mirror), 8 bounces, 2000 spp: default 50 steps x 1 pass x S = 40; the driver's --steps 20 gives
+                20 steps x 2 passes x S = 50 = the same 2000 spp
   c2            configs[1]: 1280x720, preset "lambert" (the default scene's 36 primitives, every non-emissive material
-                Lambert), 8 bounces; default S = 32 x 16 passes = the config's 512 spp
+                Lambert), 8 bounces, 512 spp: default 16 steps x 1 pass x S = 32
   c5            configs[4]: 3840x2160, preset "stress" (1,024 spheres + open Cornell box), 12 bounces; the config asks for
-                4096 spp on 8 GPUs — default here S = 4 x 16 passes = 64 spp of that very frame (a rate metric)
+                4096 spp on 8 GPUs — one GPU runs 64 spp of that very frame here (16 steps x 1 pass x S = 4; a rate metric)
 
 For N > 1 the SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
 so total work is fixed ("strong" scaling); the integer accumulators are gathered to rank 0 with one
@@ -26,10 +28,11 @@ summed over bounces and passes (device-side counter), over the wall time of the 
 ray-bounce: 76 B SoA state read + 76 B written, BASELINE.md §3) / HIP-event time of the kernel against 8 TB/s HBM;
 `valu.issue_frac` = wave-level VALU instructions per launch (SQ_INSTS_VALU, from the committed PMC summary
 profiles/pmc_counters.json, taken with this configuration) / (1,024 SIMDs x 2.4 GHz / 2 cycles x the launch time
-measured in THIS run). `cpu_baseline` times oracle/ (the CPU restatement, OpenMP) on a bounded slice of the same
-workload. `s1_mrays_per_s` is a short leg of the same frame at S = 1, the reference's own mode, one context with the
-library's own choice of frame lanes (cfg.frameLanes = 0: two ray populations on two streams at 1080p, image and loop guard
-identical to one); `s1_one_lane_mrays_per_s` the same with one lane; `s1_two_shards_two_streams_mrays_per_s` the same
+measured in THIS run). `roofline.moved_bytes_frac` prices the same launches by the bytes the fused kernels really move. `cpu_baseline` times oracle/
+(the CPU restatement, OpenMP) on a bounded slice of the same workload. `s1_mrays_per_s` is a short leg of the same frame at
+S = 1, the reference's own mode, with the default configuration (one lane, ordered on the caller's stream);
+`s1_free_running_lanes_mrays_per_s` the same for a caller that opted into free-running frame lanes (cfg.lanesFreeRun: two ray
+populations on two streams at 1080p, image and loop guard identical to one); `s1_two_shards_two_streams_mrays_per_s` the same
 frame as two pixel-band shard CONTEXTS on two streams (the multi-GPU sharding on one GPU: the loop-guard caveat applies).
 """
 import argparse
@@ -48,13 +51,39 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2   # 1,024 SIMDs, one wave64 VALU i
 BAND_ROWS = 8
 
 CONFIGS = {
-    "c2": dict(index=1, width=1280, height=720, bounces=8, preset="lambert", spp=512, samples=32, steps=16,
+    # spp: what the BASELINE config asks; run_spp: what the K timed steps of a run render together (c5: a stated share of it on
+    # one GPU); samples: S of the default run; s_range: the S a run may choose so that K x P x S = run_spp for another K
+    "c2": dict(index=1, width=1280, height=720, bounces=8, preset="lambert", spp=512, run_spp=512, samples=32, steps=16, s_range=(16, 64),
                what="36 primitives (20 spheres, 16 triangles), Lambert only"),
-    "c3": dict(index=2, width=1920, height=1080, bounces=8, preset="mixed", spp=2000, samples=40, steps=50,
+    "c3": dict(index=2, width=1920, height=1080, bounces=8, preset="mixed", spp=2000, run_spp=2000, samples=40, steps=50, s_range=(16, 64),
                what="22 spheres, 16 triangles, Lambert/Phong/Cook-Torrance/glass/mirror"),
-    "c5": dict(index=4, width=3840, height=2160, bounces=12, preset="stress", spp=4096, samples=4, steps=16,
+    "c5": dict(index=4, width=3840, height=2160, bounces=12, preset="stress", spp=4096, run_spp=64, samples=4, steps=16, s_range=(4, 4),
                what="1,024 random spheres + 12 triangles, all material classes (stream-compaction stress)"),
 }
+
+
+def plan_steps(cfg, steps=None, samples=None):
+    """(K, P, S): K timed steps of P passes of S sample lanes per pixel, K x P x S >= run_spp with equality whenever run_spp / K
+    has a divisor in the configuration's S range (c3, the driver's --steps 20: 2000 / 20 = 100 = 2 passes x S = 50; the default
+    K = 50: 1 pass x S = 40). An explicit --samples-per-pass is kept and P rounds up."""
+    K = steps if steps is not None else cfg["steps"]
+    per_step = -(-cfg["run_spp"] // K)
+    if samples is None:
+        lo, hi = cfg["s_range"]
+        fits = [d for d in range(lo, hi + 1) if per_step % d == 0]
+        samples = max(fits) if fits else (cfg["samples"] if per_step >= cfg["samples"] else max(lo, min(hi, per_step)))
+    return K, -(-per_step // samples), samples
+
+
+def moved_bytes(live, first_in=32, later_in=76, survivor_out=76, ended_out=36):
+    """HBM bytes the fused kernels actually move for one pass with `live[b]` rays entering bounce b: bounce 0
+    reads a 32-B home record instead of a 76-B pool slot; a surviving ray writes its 76-B slot; a path that ends writes 36 B
+    (its 8-bit sample word + the 32-B home record) instead."""
+    total = 0
+    for b, n in enumerate(live):
+        nxt = live[b + 1] if b + 1 < len(live) else 0
+        total += n * (first_in if b == 0 else later_in) + nxt * survivor_out + (n - nxt) * ended_out
+    return total
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -84,7 +113,8 @@ def cpu_baseline(cfg, budget_s=12.0):
     o.close()
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes (1 spp each) of {w}x{h} '{cfg['preset']}'{scaled}, {cfg['bounces']} bounces, "
-                      f"{rays} ray-bounces in {dt:.1f} s, OpenMP over rays"}
+                      f"{rays} ray-bounces in {dt:.1f} s, OpenMP over rays (bounce kernel, compaction by per-thread counts + "
+                      f"prefix, accumulate)"}
 
 
 def pmc_counters(config, samples):
@@ -100,7 +130,7 @@ def pmc_counters(config, samples):
     return None, None
 
 
-def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes=0):
+def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes=0, lanes_free_run=False):
     """The reference's own mode on the same frame: one sample per pixel per generateFrame call (CudaTracer.cu:587-647).
     shards = 1: one context, the reference's semantics to the letter. shards = K > 1: the same frame as K interleaved
     pixel-band shards (cfg.tileWorld = K, the multi-GPU sharding) in THIS process on this one GPU, each on its own stream,
@@ -110,7 +140,8 @@ def s1_leg(ptss, torch, scene, cfg, shards=1, passes=300, warmup=40, frame_lanes
     for k in range(shards):
         r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], seed=SEED, device=torch.cuda.current_device(),
                           tile_rank=k, tile_world=shards, band_rows=BAND_ROWS, sync_each_frame=False, samples_per_pass=1,
-                          frame_lanes=frame_lanes if shards == 1 else 1)   # shard contexts: one lane each (the experiment is the two contexts)
+                          frame_lanes=frame_lanes if shards == 1 else 1,   # shard contexts: one lane each (the experiment is the two contexts)
+                          lanes_free_run=lanes_free_run and shards == 1)
         r.set_stream(torch.cuda.Stream().cuda_stream if shards > 1 else torch.cuda.current_stream().cuda_stream)
         rs.append(r)
         pix.append(torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda"))
@@ -157,8 +188,7 @@ def main():
     ap.add_argument("--dump-frame", default=None, help="tests: rank 0 saves the whole-frame integer accumulator (.npy)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    steps = args.steps if args.steps is not None else cfg["steps"]
-    samples = args.samples_per_pass if args.samples_per_pass is not None else cfg["samples"]
+    steps, passes_per_step, samples = plan_steps(cfg, args.steps, args.samples_per_pass)
     W, H, B, preset = cfg["width"], cfg["height"], cfg["bounces"], cfg["preset"]
 
     import torch
@@ -196,7 +226,11 @@ def main():
     scene = ptss.Scene(preset)
     r = ptss.Renderer(scene, W, H, max_iterations=B, seed=SEED, device=local_rank,
                       tile_rank=rank, tile_world=world, band_rows=BAND_ROWS, sync_each_frame=False,
-                      time_kernels=not args.no_kernel_timing, samples_per_pass=samples)
+                      time_kernels=not args.no_kernel_timing, samples_per_pass=samples,
+                      # Nothing is enqueued on this stream between two frames (the one reader of the accumulator, the gather, comes
+                      # after the last frame and behind its join), so the context may run its lanes free (include/ptss.h
+                      # lanesFreeRun): the library then gives a small shard of a multi-GPU frame two lanes, a wide pass one.
+                      lanes_free_run=True)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     # torch owns the buffers that leave the renderer: accumulator (gathered) and display pixels
@@ -217,7 +251,8 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        r.generate_frame(pix.data_ptr())
+        for _ in range(passes_per_step):
+            r.generate_frame(pix.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -245,39 +280,44 @@ def main():
         import numpy as np
         np.save(args.dump_frame, acc.cpu().numpy())
     rays = r.total_ray_bounces() - rays0
+    # bounce-kernel BUSY time of this rank: the union of its launches' event intervals (one lane: the sum of the launch
+    # durations; lanes overlap in time, and a sum of their durations would not be a time)
     kms, klaunches = (0.0, 0) if args.no_kernel_timing else r.bounce_kernel_time()
     lanes = r.frame_lanes
-    if lanes > 1:   # the lanes' kernels overlap in time: a sum of their durations is not a launch time (a small shard of a
-        kms, klaunches = 0.0, 0   # multi-GPU frame gets two lanes); the roofline object is reported for one-lane runs only
-    stats = torch.tensor([elapsed, float(rays), kms, float(klaunches)], dtype=torch.float64, device=coll_dev)
+    live = [int(x) for x in r.live_counts()]      # this rank's rays entering each bounce of the last pass
+    moved = float(moved_bytes(live)) * (float(rays) / max(sum(live), 1))   # scaled from the last pass to the timed region
+    stats = torch.tensor([elapsed, float(rays), kms, float(klaunches), moved], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, rays, kms, klaunches = float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3])
+        elapsed, rays, kms, klaunches, moved = float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3]), float(sm[4])
 
     if rank == 0:
-        spp_run = steps * samples
+        spp_run = steps * passes_per_step * samples
+        asks = (f"= BASELINE configs[{cfg['index']}]'s {cfg['spp']} spp" if spp_run == cfg["spp"] else
+                f"run (BASELINE configs[{cfg['index']}] asks {cfg['spp']} spp; a rate metric)")
         out = {
-            "metric": f"Mrays/sec at {W}x{H}, {B} bounces, {spp_run} spp run (BASELINE configs[{cfg['index']}] asks {cfg['spp']} spp; "
-                      f"a rate metric; ray = one live ray processed in one bounce)",
+            "metric": f"Mrays/sec at {W}x{H}, {B} bounces, {spp_run} spp {asks}; ray = one live ray processed in one bounce",
             "value": round(rays / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "passes_per_step": passes_per_step,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"configs[{cfg['index']}]: {W}x{H} '{preset}' preset ({cfg['what']}), {B} bounces, "
-                                   f"{spp_run} spp = {steps} passes x {samples} sample lanes per pixel",
+                                   f"{spp_run} spp = {steps} steps x {passes_per_step} pass(es) x {samples} sample lanes per pixel",
                        "name": args.config,
                        "samples_per_pass": samples,
                        "frame_lanes": lanes,
+                       "lanes_free_run": True,
                        "sharding": f"{world} rank(s), interleaved {BAND_ROWS}-row pixel bands"
                                    + (", one RCCL gather of the uint3 accumulator" if world > 1 else ""),
                        "seed": SEED},
@@ -285,31 +325,48 @@ def main():
                       "and cannot be built here (DESIGN.md §4)",
             "mpaths_per_s": round(W * H * spp_run / elapsed / 1e6, 2),
             "ray_bounces": int(rays),
-            "live_counts": [int(x) for x in r.live_counts()] if world == 1 else None,  # rays entering each bounce, last pass
+            "live_counts": live if world == 1 else None,  # rays entering each bounce, last pass
         }
         if kms > 0:
             # per launch: algorithmic bytes of the rays one launch processes / that launch's duration;
             # averaged over every bounce-kernel launch of the timed region (all ranks)
+            # (N ranks: kms is the SUM of the ranks' busy times and rays their total, so rays / (kms / N) would be the
+            # aggregate rate; per GPU, which is what a per-device peak prices, it is rays / kms)
             gbs = rays * BYTES_PER_RAY_BOUNCE / (kms * 1e-3) / 1e9
             hbm_frac = gbs / HBM_PEAK_GBS
             avg_launch_s = kms * 1e-3 / max(klaunches, 1)
             roof = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(hbm_frac, 4), "traffic": None,
+                # the same launches priced by the bytes the fused kernels really move (bounce 0 reads a 32-B home record, an
+                # ended path writes 36 B): `frac` is SURVEY §8(d)'s 152 B per ray-bounce, this is the honest lower figure
+                "moved_bytes_frac": round(moved / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "moved_bytes_per_ray_bounce": round(moved / max(rays, 1), 1),
                 "kernel": "ptss::bounceKernel", "launches": int(klaunches),
                 "avg_launch_us": round(avg_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": round(rays * BYTES_PER_RAY_BOUNCE / max(klaunches, 1)),
                 "kernel_grays_per_s": round(rays / (kms * 1e-3) / 1e9, 3),
+                "per": "GPU" if world > 1 else "launch",
             }
-            pmc, src = pmc_counters(args.config, samples) if world == 1 else (None, None)
+            if lanes > 1:
+                roof["lanes_note"] = (f"{lanes} frame lanes: their kernels overlap in time, so the launch time is the union of the "
+                                      f"launches' event intervals divided by the launch count — an effective, not an isolated, duration")
+            # the PMC summary is per launch of the N = 1 run at the default S; a rank of N renders 1 / N of the frame, and another S
+            # scales a launch's rays by S / S_default: counters per launch scale with the rays of a launch
+            pmc, src = pmc_counters(args.config, cfg["samples"])
             if pmc:
-                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = src + " — measured per launch in separate --pmc passes, not in this run"
+                scale = (samples / cfg["samples"]) / world
+                how = "measured per launch in separate --pmc passes, not in this run"
+                if scale != 1.0:
+                    how += f"; scaled by {scale:.4g} = rays per launch of this run / of the profiled one ({world} rank(s), S = {samples})"
+                roof["traffic"] = round(pmc.get("hbm_bytes_per_launch") * scale) if pmc.get("hbm_bytes_per_launch") else None
+                roof["traffic_source"] = src + " — " + how
                 insts = pmc.get("valu_insts_per_launch")
                 if insts:
+                    insts = insts * scale
                     issue = insts / avg_launch_s / VALU_PEAK_WAVE_INSTR_PER_S
                     roof["valu"] = {
-                        "insts_per_launch": insts, "issue_frac": round(issue, 4),
+                        "insts_per_launch": round(insts), "issue_frac": round(issue, 4),
                         "lanes_active": pmc.get("valu_lanes_active"),
                         "insts_per_64_ray_tile": pmc.get("valu_insts_per_tile_mid_bounce"),
                         "peak": "1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
@@ -325,11 +382,12 @@ def main():
                             "the HBM and VALU-issue fractions")
             out["roofline"] = roof
         if world == 1 and not args.no_s1_leg:
-            v, ms = s1_leg(ptss, torch, scene, cfg)               # the library's own choice of frame lanes (2 at 1080p)
+            v, ms = s1_leg(ptss, torch, scene, cfg)               # the default configuration: ordered on the caller's stream, one lane
             out["s1_mrays_per_s"] = v
             out["s1_ms_per_pass"] = ms
-            v1, _ = s1_leg(ptss, torch, scene, cfg, frame_lanes=1)  # one ray population on one stream
-            out["s1_one_lane_mrays_per_s"] = v1
+            vf, msf = s1_leg(ptss, torch, scene, cfg, lanes_free_run=True)  # opt-in (cfg.lanesFreeRun): the library's lane choice, 2 at 1080p
+            out["s1_free_running_lanes_mrays_per_s"] = vf
+            out["s1_free_running_lanes_ms_per_pass"] = msf
             v2, ms2 = s1_leg(ptss, torch, scene, cfg, shards=2, frame_lanes=1)
             out["s1_two_shards_two_streams_mrays_per_s"] = v2
             out["s1_two_shards_two_streams_ms_per_pass"] = ms2

@@ -108,15 +108,16 @@ struct ptss_context {
     int gridCap = 0;             // workgroups per shard at most = 16 resident rounds of this scene's bounce kernel (0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     unsigned frameIndex = 0;
-    // bounce-kernel timing (cfg.timeKernels)
+    // bounce-kernel timing (cfg.timeKernels): every launch is bracketed by two events on ITS stream; a finished pair becomes
+    // an interval [start, end) in ms since evEpoch. ptss_bounce_kernel_time reports the UNION of the intervals: with one lane
+    // that is the sum of the launch durations, with several lanes (whose kernels overlap in time) the time during which at
+    // least one bounce kernel was running — the figure a launch-time roofline needs.
     std::vector<EventPair> evFree, evBusy;
-    double kernelMs = 0.0;
-    unsigned long long kernelLaunches = 0;
+    std::vector<std::pair<double, double>> kernelSpans;
+    hipEvent_t evEpoch = nullptr;
+    unsigned int timeoutsSeen = 0;   // ptss_guard_timeouts value already reported as PTSS_ETIMEOUT
 };
 constexpr int kTotalWords = ptss::kMaxLanes + 8 + 1;
-#ifndef PTSS_LANE_ALWAYS_FORK
-#define PTSS_LANE_ALWAYS_FORK 0   // 1: every frame starts with a fork from the caller's stream (A/B timing only)
-#endif
 
 namespace {
 
@@ -402,10 +403,11 @@ void drainKernelEvents(ptss_context* c, bool wait) {
         EventPair p = c->evBusy[i];
         hipError_t q = wait ? hipEventSynchronize(p.b) : hipEventQuery(p.b);
         if (q == hipSuccess) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-                c->kernelMs += ms;
-                c->kernelLaunches += 1;
+            float start = 0, ms = 0;   // start since the epoch (coarse at large values), duration from the pair itself (exact)
+            if (hipEventElapsedTime(&start, c->evEpoch, p.a) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+            {
+                if (c->kernelSpans.size() >= (1u << 20)) c->kernelSpans.clear();   // nobody is asking (ptss_bounce_kernel_time empties it)
+                c->kernelSpans.emplace_back((double)start, (double)start + (double)ms);
             }
             c->evFree.push_back(p);
         } else {
@@ -416,11 +418,24 @@ void drainKernelEvents(ptss_context* c, bool wait) {
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
 }
 
+// Frame lanes: did a lane give up waiting for a peer since the last check (FrameBuffers::guardTimeouts)? Called by the
+// entry points that have just synchronised; one 4-byte read-back, and only in contexts with more than one lane.
+int checkLaneTimeouts(ptss_context* c) {
+    if (c->lanes.size() < 2) return PTSS_OK;
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpy(&v, c->dTotal + ptss::kMaxLanes + 8, sizeof(v), hipMemcpyDeviceToHost));
+    if (v != c->timeoutsSeen) {
+        c->timeoutsSeen = v;
+        return fail(PTSS_ETIMEOUT, "a frame lane gave up waiting for a peer lane: the frame's loop guard was decided without it");
+    }
+    return PTSS_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int ptss_version(void) { return 100; }
+int ptss_version(void) { return PTSS_VERSION; }
 
 const char* ptss_error_string(int code) {
     switch (code) {
@@ -430,6 +445,7 @@ const char* ptss_error_string(int code) {
         case PTSS_ENODEVICE: return "no usable HIP device";
         case PTSS_ENOMEM: return "out of memory";
         case PTSS_ERANGE: return "buffer too small or index out of range";
+        case PTSS_ETIMEOUT: return "a frame lane timed out waiting for a peer lane";
         default: return "unknown error";
     }
 }
@@ -439,6 +455,7 @@ const char* ptss_last_error_detail(void) { return g_detail.c_str(); }
 int ptss_default_config(ptss_render_config* cfg) {
     if (!cfg) return fail(PTSS_EINVAL, "cfg is null");
     memset(cfg, 0, sizeof(*cfg));
+    cfg->structSize = (unsigned int)sizeof(*cfg);
     cfg->width = 512;  // DIM, CudaUtils.h:7
     cfg->height = 512;
     cfg->seed = 0x5EEDull;
@@ -453,11 +470,15 @@ int ptss_default_config(ptss_render_config* cfg) {
     cfg->samplesPerPass = 1;
     cfg->everySphereLoop = 0;
     cfg->frameLanes = 0;
+    cfg->lanesFreeRun = 0;
     return PTSS_OK;
 }
 
 int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, ptss_context** out) {
     if (!scene || !cfg || !out) return fail(PTSS_EINVAL, "null argument");
+    if (cfg->structSize != (unsigned int)sizeof(ptss_render_config))
+        return fail(PTSS_EINVAL, "cfg->structSize is not this library's sizeof(ptss_render_config): the caller was built against another "
+                                 "ptss.h (compare ptss_version() with PTSS_VERSION) or did not start from ptss_default_config");
     if (cfg->width <= 0 || cfg->height <= 0 || (long long)cfg->width * cfg->height > (1ll << 31) - 256)
         return fail(PTSS_EINVAL, "bad frame size");
     if (cfg->maxIterations == 0 || cfg->maxIterations > (unsigned)ptss::kMaxBounces)
@@ -525,7 +546,9 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         // 800x600 (0.48 M) 7,490 / 7,900; 640x480 (0.31 M) 5,480 / 5,380; 512x512 (0.26 M) 4,730 / 4,570 — below ~0.2 ms a pass is ten launch
         // latencies, nothing to overlap; 1920x1080 S = 40 (83 M) 17,760 / 17,750. Four lanes (five streams with the caller's) share
         // hardware queues and serialise. (With the lanes coupled through stream events the gain at 1280x720 was inside the noise.)
-        if (numLanes == 0) numLanes = (rays >= (3ull << 17) && rays <= (1ull << 24)) ? 2 : 1;
+        // All of that is the FREE-RUNNING mode (cfg.lanesFreeRun); ordered strictly on the caller's stream — a fork and a join per
+        // frame — two lanes ran at 13,180 against one lane's 13,800, so the library's own choice is then one lane.
+        if (numLanes == 0) numLanes = (cfg->lanesFreeRun && rays >= (3ull << 17) && rays <= (1ull << 24)) ? 2 : 1;
     }
     c->lanes.resize((size_t)numLanes);
     uint32_t shardCount0[ptss::kMaxLanes][ptss::kShards] = {{0}};
@@ -617,6 +640,7 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
     }
     CREATE_TRY(hipEventCreate(&c->evStart));
     CREATE_TRY(hipEventCreate(&c->evStop));
+    CREATE_TRY(hipEventCreate(&c->evEpoch));
 
     // curandSetupKernel (CudaTracer.cu:722-724): per-pixel subsequence via the 2^67 jump table
     {
@@ -628,7 +652,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         hipError_t e2 = e1;
         if (e1 == hipSuccess && c->numPixels > 0)
             e2 = ptss::launchRngInit(nullptr, c->dRngHome, c->capacity, c->samples, c->tile, cfg->seed, dTable);
-        hipError_t e3 = e2 == hipSuccess ? hipDeviceSynchronize() : e2;
+        hipError_t e3 = e2 == hipSuccess ? hipEventRecord(c->evEpoch, nullptr) : e2;
+        if (e3 == hipSuccess) e3 = hipDeviceSynchronize();
         (void)hipFree(dTable);
         CREATE_TRY(e3);
     }
@@ -688,6 +713,7 @@ int ptss_destroy(ptss_context* c) {
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->evEpoch) (void)hipEventDestroy(c->evEpoch);
     (void)hipFree(c->dScene);
     (void)hipFree(c->dSceneAlt);
     (void)hipFree(c->dRngHome);
@@ -771,10 +797,13 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
 
     // Several lanes: each runs on its own stream, forked from the caller's here and joined into it below; their
     // launches are issued round-robin, bounce by bounce, so that the streams advance together.
-    // The fork is needed only when the caller's stream did something the lanes depend on (the clear of a reset, the
-    // camera precomputes) — otherwise a lane's next frame depends on nothing but its own previous one, and the lanes run
-    // on, frame after frame, while the caller's stream merely waits for each frame's end (the join below).
-    if (K > 1 && (forkNeeded || c->frameIndex == 0 || PTSS_LANE_ALWAYS_FORK)) {
+    // STRICT ordering (the default): every frame forks, so the lanes start behind whatever the caller put on its stream
+    // before this call — a reader of the previous frame's pixels or accumulator, a zero-fill, a newly bound buffer's writer.
+    // FREE-RUNNING (cfg.lanesFreeRun, opt-in): the fork happens only when the library's own work on the caller's stream
+    // requires it (the clear of a reset, the camera precomputes) — otherwise a lane's next frame depends on nothing but
+    // its own previous one, and the lanes run on, frame after frame, while the caller's stream merely waits for each
+    // frame's end (the join below); the caller has promised not to touch the buffers in between (include/ptss.h).
+    if (K > 1 && (forkNeeded || c->frameIndex == 0 || !c->cfg.lanesFreeRun)) {
         HIP_TRY(hipEventRecord(c->evFork, st));
         for (Lane& ln : c->lanes) HIP_TRY(hipStreamWaitEvent(ln.stream, c->evFork, 0));
     }
@@ -860,6 +889,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         HIP_TRY(hipEventRecord(c->evStop, st));
         HIP_TRY(hipEventSynchronize(c->evStop));
         HIP_TRY(hipEventElapsedTime(&c->lastMs, c->evStart, c->evStop));
+        return checkLaneTimeouts(c);
     }
     return PTSS_OK;
 }
@@ -960,7 +990,7 @@ int ptss_local_rows(const ptss_context* c, int* rows, int cap, int* count) {
 int ptss_synchronize(ptss_context* c) {
     if (!c) return fail(PTSS_EINVAL, "ctx is null");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_read_accumulator(ptss_context* c, uint32_t* host, size_t count) {
@@ -968,7 +998,7 @@ int ptss_read_accumulator(ptss_context* c, uint32_t* host, size_t count) {
     if (count != (size_t)3 * c->numPixels) return fail(PTSS_ERANGE, "count must be 3 * local pixels");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(host, c->dAccum, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_read_float_accumulator(ptss_context* c, float* host, size_t count) {
@@ -986,7 +1016,7 @@ int ptss_read_float_accumulator(ptss_context* c, float* host, size_t count) {
             for (size_t k = 0; k < count; ++k) host[k] = host[k] + lane[k];
         }
     }
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_read_pixels(ptss_context* c, const ptss_uchar4* dev, ptss_uchar4* host, size_t count) {
@@ -994,7 +1024,7 @@ int ptss_read_pixels(ptss_context* c, const ptss_uchar4* dev, ptss_uchar4* host,
     if (count > c->numPixels) return fail(PTSS_ERANGE, "count exceeds local pixels");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(host, dev, count * sizeof(ptss_uchar4), hipMemcpyDeviceToHost));
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_read_rng_state(ptss_context* c, size_t local_pixel, uint32_t* out6) { return ptss_read_rng_state_lane(c, local_pixel, 0, out6); }
@@ -1039,7 +1069,7 @@ int ptss_live_counts(ptss_context* c, uint32_t* out, int cap, int* n) {
         out[i] = stopped ? 0u : total;
     }
     *n = numIterations;
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
@@ -1049,7 +1079,7 @@ int ptss_total_ray_bounces(ptss_context* c, unsigned long long* out) {
     HIP_TRY(hipMemcpy(perLane, c->dTotal, sizeof(perLane), hipMemcpyDeviceToHost));
     *out = 0;
     for (size_t k = 0; k < c->lanes.size(); ++k) *out += perLane[k];
-    return PTSS_OK;
+    return checkLaneTimeouts(c);
 }
 
 int ptss_guard_timeouts(ptss_context* c, unsigned int* out) {
@@ -1081,12 +1111,28 @@ int ptss_debug_counters(ptss_context* c, unsigned long long* out8) {
 int ptss_bounce_kernel_time(ptss_context* c, double* total_ms, unsigned long long* launches) {
     if (!c || !total_ms || !launches) return fail(PTSS_EINVAL, "null argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (const Lane& ln : c->lanes)
+        if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     drainKernelEvents(c, true);
-    *total_ms = c->kernelMs;
-    *launches = c->kernelLaunches;
-    c->kernelMs = 0.0;
-    c->kernelLaunches = 0;
-    return PTSS_OK;
+    // union of the launch intervals (one lane: they do not overlap, and this is the sum of the durations)
+    std::sort(c->kernelSpans.begin(), c->kernelSpans.end());
+    double busy = 0.0, curA = 0.0, curB = -1.0;
+    for (const auto& sp : c->kernelSpans) {
+        if (curB < curA || sp.first > curB) {
+            if (curB >= curA) busy += curB - curA;
+            curA = sp.first;
+            curB = sp.second;
+        } else if (sp.second > curB) {
+            curB = sp.second;
+        }
+    }
+    if (curB >= curA) busy += curB - curA;
+    *total_ms = busy;
+    *launches = c->kernelSpans.size();
+    c->kernelSpans.clear();
+    HIP_TRY(hipEventRecord(c->evEpoch, c->stream));   // a fresh epoch for the next window: float32 ms stay fine-grained
+    HIP_TRY(hipEventSynchronize(c->evEpoch));
+    return checkLaneTimeouts(c);
 }
 
 }  // extern "C"

@@ -185,7 +185,8 @@ struct FrameBuffers {
     uint32_t frameSeq;                              // frames finished before this one (what the peers' counters must have reached)
     uint32_t joinsFrame;                            // 1 in the LAST lane: its flushKernel also waits for the peers' flushes of THIS frame (all of them
                                                     // enqueued before it), so that one event behind it orders the caller's stream after the whole frame
-    uint32_t* guardTimeouts;         // incremented if a peer's word never arrived (must stay 0; ptss_generate_frame reports it)
+    uint32_t* guardTimeouts;         // incremented when a wait for a peer lane expired (must stay 0). The host reads it at its next
+                                     // synchronising call and returns PTSS_ETIMEOUT (ptss_api.hip checkLaneTimeouts)
 };
 
 // ---- launchers (ptss_kernels.hip) --------------------------------------------------------------

@@ -1264,10 +1264,20 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 // lane's own count `own` is not above the threshold. Waits (bounded) until every workgroup of each peer's bounce b - 1 has
 // ended (the peer's done counters reach `target[p]`), then adds the peer's sixteen shard counters of bounce b.
 // Called by at most one workgroup per shard of a lane that holds <= 128 rays, and by flushKernel.
+// Every wait for a peer lane is bounded by TIME — about two seconds of the 100 MHz real-time counter (s_memrealtime), whatever
+// a poll costs under load —: a peer stream that never runs must not hang the device. A wait that expires counts itself in
+// guardTimeouts, which the host turns into PTSS_ETIMEOUT at its next synchronising call (ptss_api.hip checkLaneTimeouts).
+constexpr unsigned long long kPeerWaitTicks = 200000000ull;
+__device__ __forceinline__ bool peerWaitExpired(unsigned long long& since) {
+    const unsigned long long now = wall_clock64();
+    if (since == 0ull) since = now | 1ull;
+    return now - since > kPeerWaitTicks;
+}
+
 __device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int bounce, uint32_t own, const uint32_t* target) {
     uint32_t total = own;
     for (uint32_t p = 0; p < fb.numPeers; ++p) {
-        uint32_t spins = 0;
+        unsigned long long since = 0ull;
         for (;;) {
             uint32_t ended = 0;
             for (int s = 0; s < kShards; ++s)
@@ -1277,7 +1287,7 @@ __device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int b
             // re-arms only after this lane's frame)
             if ((int32_t)(ended - target[p]) >= 0) break;
             __builtin_amdgcn_s_sleep(64);
-            if (++spins > (1u << 20)) {  // ~ seconds: a peer stream that never runs; do not hang the device
+            if (peerWaitExpired(since)) {
                 if (threadIdx.x == 0) atomicAdd(fb.guardTimeouts, 1u);
                 break;
             }
@@ -1836,10 +1846,10 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
     // wait until every peer has finished that frame (its flushKernel was enqueued before this one: no deadlock in a shared queue).
     if (threadIdx.x == 0)
         for (uint32_t p = 0; p < fb.numPeers; ++p) {
-            uint32_t spins = 0;
+            unsigned long long since = 0ull;
             while ((int32_t)(__hip_atomic_load(fb.peerFrameDone[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fb.frameSeq) < 0) {
                 __builtin_amdgcn_s_sleep(64);
-                if (++spins > (1u << 20)) {
+                if (peerWaitExpired(since)) {
                     atomicAdd(fb.guardTimeouts, 1u);
                     break;
                 }
@@ -1853,21 +1863,31 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
         fb.lastCounts[countIndex(b, s)] = (b <= numBounces) ? fb.counts[countIndex(b, s)] : 0u;
         fb.countsNext[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
     }
-    // this lane has finished the frame: every read of a peer's counters (thread 0, above) has returned by now
+    // This lane has finished the frame: every read of a peer's counters (thread 0, above) has returned by now, and what this
+    // kernel wrote — finishPath's accumulator / pixel / float-sum / RNG words of the leftover rays, lastCounts, countsNext, the
+    // ray-bounce total — is PUBLISHED before the frame-done word: every wave drains its stores, the workgroup meets, and one
+    // lane writes this XCD's L2 back (agent-scope release; once per frame and lane, in a 128-thread kernel) before it stores
+    // the word. The join below depends on that: the caller's stream is ordered behind the LAST lane's flush only, and the
+    // end-of-kernel write-back of that kernel covers its own XCD's L2, not the one a peer's flush ran on.
     if (fb.numPeers != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            if (fb.joinsFrame)   // the last lane's flush ends only when the whole frame has (the join event sits behind it)
+            if (fb.joinsFrame) {  // the last lane's flush ends only when the whole frame has (the join event sits behind it)
                 for (uint32_t p = 0; p < fb.numPeers; ++p) {
-                    uint32_t spins = 0;
+                    unsigned long long since = 0ull;
                     while ((int32_t)(__hip_atomic_load(fb.peerFrameDone[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fb.frameSeq + 1u)) < 0) {
                         __builtin_amdgcn_s_sleep(64);
-                        if (++spins > (1u << 20)) {
+                        if (peerWaitExpired(since)) {
                             atomicAdd(fb.guardTimeouts, 1u);
                             break;
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one poll loop per peer, then ONE acquire
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back has completed before the word goes out (hipcc may drop the fence's own wait)
             __hip_atomic_store(fb.myFrameDone, fb.frameSeq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

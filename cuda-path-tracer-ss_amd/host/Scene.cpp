@@ -236,6 +236,7 @@ void Scene::makeLambertOnly() {
 bool Scene::buildPreset(const std::string& preset) {
     // "<name>@rtl": the reference's random-sphere generators with their position arguments drawn right to left
     std::string name = preset;
+    positionDrawsRightToLeft = false;   // a property of THIS build, not of the object: a later preset without the suffix draws left to right again
     const size_t at = name.find("@rtl");
     if (at != std::string::npos && at + 4 == name.size()) {
         positionDrawsRightToLeft = true;

@@ -29,10 +29,11 @@ class PtssError(RuntimeError):
 
 
 class RenderConfig(C.Structure):
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("seed", C.c_ulonglong), ("maxIterations", C.c_uint),
+    _fields_ = [("structSize", C.c_uint), ("width", C.c_int), ("height", C.c_int), ("seed", C.c_ulonglong), ("maxIterations", C.c_uint),
                 ("device", C.c_int), ("tileRank", C.c_int), ("tileWorld", C.c_int), ("bandRows", C.c_int),
                 ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int),
-                ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int), ("frameLanes", C.c_int)]
+                ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int), ("frameLanes", C.c_int),
+                ("lanesFreeRun", C.c_int)]
 
 
 _host = None
@@ -200,7 +201,7 @@ class Renderer:
 
     def __init__(self, scene, width, height, max_iterations=15, seed=0x5EED, device=0, tile_rank=0, tile_world=1,
                  band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1,
-                 every_sphere_loop=False, frame_lanes=0):
+                 every_sphere_loop=False, frame_lanes=0, lanes_free_run=False):
         L = device_lib()
         cfg = RenderConfig()
         _check(L.ptss_default_config(C.byref(cfg)))
@@ -215,6 +216,7 @@ class Renderer:
         cfg.samplesPerPass = samples_per_pass
         cfg.everySphereLoop = 1 if every_sphere_loop else 0
         cfg.frameLanes = frame_lanes
+        cfg.lanesFreeRun = 1 if lanes_free_run else 0
         self.cfg = cfg
         self._scene = scene  # keep the arrays alive during create
         self._ctx = C.c_void_p()

@@ -24,10 +24,16 @@ extern "C" {
 #define PTSS_ENODEVICE (-3)/* no usable HIP device */
 #define PTSS_ENOMEM (-4)   /* host or device allocation failed */
 #define PTSS_ERANGE (-5)   /* output buffer too small / index out of range */
+#define PTSS_ETIMEOUT (-6) /* frame lanes only: a lane gave up waiting for a peer lane (a stream that did not run for ~2 s); the
+                              frame's loop guard was decided without the peer, so the buffers may hold a different image */
+#define PTSS_VERSION 300   /* what ptss_version() of a matching library returns; bumped whenever a struct below changes */
 
 typedef struct ptss_context ptss_context; /* ≙ ProgramData + RendererData + every cudaMalloc of main() */
 
 typedef struct ptss_render_config {
+    unsigned int structSize;     /* sizeof(ptss_render_config) as the CALLER compiled it (ptss_default_config fills it in);
+                                    ptss_create refuses any other value, so a binding built against an older header fails
+                                    loudly instead of being read past its end */
     int width, height;           /* full frame; the reference's compile-time DIM x DIM (CudaUtils.h:7) */
     unsigned long long seed;     /* curand_init seed; the reference passes clock64() (CudaTracer.cu:28) */
     unsigned int maxIterations;  /* ProgramData::maxIterations, default 15 (CudaTracer.h:39) */
@@ -54,10 +60,20 @@ typedef struct ptss_render_config {
     int everySphereLoop;
     /* Frame lanes: the frame traced as K ray populations on K streams of the device, the tail of one lane's launches
      * overlapping the other lanes' kernels. The image — loop guard included — does not depend on K.
-     * 0 = chosen from the size of a pass (2 for 3*2^17..2^24 rays per pass, e.g. 800x600 ... 3840x2160 at one sample per tick;
-     * else 1),
-     * 1..4 = that many. */
+     * 0 = the library's choice: ONE lane, unless lanesFreeRun is set (then 2 for 3*2^17..2^24 rays per pass, e.g. 800x600 ...
+     * 3840x2160 at one sample per tick, else 1); 1..4 = that many. */
     int frameLanes;
+    /* Stream ordering of a context with more than one lane. 0 (default): STRICT — like a one-lane context the call is
+     * ordered on the caller's stream: the lanes of every frame start behind whatever the caller enqueued on its stream before
+     * the call, and the stream continues behind the whole frame, so work enqueued between two ptss_generate_frame calls
+     * (a copy of dev_pixels, a gather or a zero-fill of the bound accumulator, ...) sees exactly the frames before it. With that
+     * fork and join every frame two lanes are no faster than one (measured, profiles/README.md). 1: FREE-RUNNING — the lanes are
+     * forked from the caller's stream only on a reset or camera change and run on from frame to frame (this is where lanes
+     * gain: +15-18 % at 1080p, one sample per tick); the caller's stream still continues behind each frame, but the NEXT frame's
+     * kernels do not wait for anything the caller enqueued after the previous call. Opt in only if, between two calls,
+     * nothing touches dev_pixels, the accumulator or the float sums on the device — or call ptss_synchronize() /
+     * ptss_request_reset() first. */
+    int lanesFreeRun;
 } ptss_render_config;
 
 /* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */
@@ -116,8 +132,10 @@ int ptss_bounce_kernel_time(ptss_context* ctx, double* total_ms, unsigned long l
 
 /* Frame lanes this context runs (cfg.frameLanes resolved). */
 int ptss_frame_lanes(const ptss_context* ctx, int* out);
-/* How often a lane gave up waiting for a peer lane's live count (a stream that never ran): always 0 in a healthy
- * process; a non-zero value means the loop guard of that frame was decided without the peer. */
+/* How often a lane gave up waiting for a peer lane's live count (a stream that did not run for ~2 s): always 0 in a healthy
+ * process; a non-zero value means the loop guard of that frame was decided without the peer. Every synchronising entry
+ * point (ptss_synchronize, ptss_read_*, ptss_live_counts, ptss_total_ray_bounces, ptss_bounce_kernel_time, and
+ * ptss_generate_frame with syncEachFrame) returns PTSS_ETIMEOUT once when this count has grown since the last check. */
 int ptss_guard_timeouts(ptss_context* ctx, unsigned int* out);
 
 /* Diagnostic builds only (-DPTSS_DIAG=<bits>, csrc/ptss_diag.h, tools/build_variants.py): the eight counter words of that

@@ -645,14 +645,44 @@ void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
             CurandState& st = c->literalSlotRng ? c->curandStates[slot] : c->curandStates[(long)ray.lane * N + ray.pixelOffset];
             pathTraceOne(c->data, ray, st, isLast);
         }
-        if (!isLast) {  // :626-632, stable
-            scratch.assign(c->rays.begin(), c->rays.begin() + numRays);
+        if (!isLast) {  // :626-632 thrust::partition, made stable: actives first, both groups in slot order
+            // (parallel: every thread counts the actives of its own contiguous chunk, a prefix over the threads gives each chunk
+            // its two destinations, then every thread moves its chunk — the order inside and between chunks is kept)
+            scratch.resize((size_t)numRays);
+            const int T = omp_get_max_threads();
+            std::vector<long> actives((size_t)T + 1, 0), headOf((size_t)T + 1, 0), tailOf((size_t)T + 1, 0);
             long head = 0;
-            for (long k = 0; k < numRays; ++k)
-                if (scratch[k].active) c->rays[head++] = scratch[k];
-            long tail = head;
-            for (long k = 0; k < numRays; ++k)
-                if (!scratch[k].active) c->rays[tail++] = scratch[k];
+#pragma omp parallel num_threads(T)
+            {
+                const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+                const long lo = numRays * t / nt, hi = numRays * (t + 1) / nt;
+                long mine = 0;
+                for (long k = lo; k < hi; ++k) {
+                    scratch[k] = c->rays[k];
+                    mine += scratch[k].active ? 1 : 0;
+                }
+                actives[t] = mine;
+#pragma omp barrier
+#pragma omp single
+                {
+                    long total = 0;
+                    for (int q = 0; q < nt; ++q) total += actives[q];
+                    long h = 0, tl = total;
+                    for (int q = 0; q < nt; ++q) {
+                        const long qlo = numRays * q / nt, qhi = numRays * (q + 1) / nt;
+                        headOf[q] = h;
+                        tailOf[q] = tl;
+                        h += actives[q];
+                        tl += (qhi - qlo) - actives[q];
+                    }
+                    head = total;
+                }   // (implicit barrier)
+                long h = headOf[t], tl = tailOf[t];
+                for (long k = lo; k < hi; ++k) {
+                    if (scratch[k].active) c->rays[h++] = scratch[k];
+                    else c->rays[tl++] = scratch[k];
+                }
+            }
             numRays = head;
         }
     }
@@ -660,12 +690,21 @@ void oracle_generate_frame(oracle_ctx* c, ptss_uchar4* pixels, int ticks) {
     // writeToPixelsKernel :63-104 over all slots: every sample is tone-mapped on its own, then summed
     const int sample = ticks - c->lastResetTick;
     const float inverseTicks = 1.f / (float)(S * (sample + 1));  // S = 1: 1.f / (ticks + 1), :94
+    // (parallel over slots: a stream's float sum and last radiance belong to one slot; the integer sums of a pixel receive
+    // S samples from S slots — integer adds commute, so atomic adds give the sequential loop's sums exactly)
+#pragma omp parallel for schedule(static)
     for (long slot = 0; slot < M; ++slot) {
         const Ray& ray = c->rays[slot];
         const long p = ray.pixelOffset, stream = (long)ray.lane * N + p;
         const float rad[3] = {ray.radiance0.x, ray.radiance0.y, ray.radiance0.z};
         for (int ch = 0; ch < 3; ++ch) {
-            c->totalPixelColors[3 * p + ch] += quantizeSample(rad[ch]);
+            const uint32_t q = quantizeSample(rad[ch]);
+            if (S == 1) {
+                c->totalPixelColors[3 * p + ch] += q;
+            } else {
+#pragma omp atomic
+                c->totalPixelColors[3 * p + ch] += q;
+            }
             c->floatSum[3 * stream + ch] += rad[ch];
             c->lastRadiance0[3 * stream + ch] = rad[ch];
         }

@@ -82,6 +82,35 @@ def test_default_config_and_argument_errors():
     assert L.ptss_destroy(None) == 0
 
 
+def test_version_and_struct_size_guard_the_config_layout():
+    """ptss_render_config has grown across rounds: a binding built against an older header must fail loudly in ptss_create
+    (cfg.structSize) instead of being read past its end, and ptss_version() names the layout."""
+    L = ptss.device_lib()
+    header = open(os.path.join(INC, "ptss.h")).read()
+    assert L.ptss_version() == int(re.search(r"#define PTSS_VERSION (\d+)", header).group(1)) == 300
+    cfg = ptss.RenderConfig()
+    assert L.ptss_default_config(C.byref(cfg)) == 0
+    assert cfg.structSize == C.sizeof(ptss.RenderConfig) and cfg.lanesFreeRun == 0 and cfg.frameLanes == 0
+    # the C compiler's sizeof agrees with the ctypes mirror
+    src = '#include <stdio.h>\n#include "ptss.h"\nint main(void){printf("%zu", sizeof(ptss_render_config)); return 0;}\n'
+    exe = os.path.join(ROOT, "tests", "_sizeof_cfg")
+    try:
+        subprocess.run(["gcc", "-std=c99", "-I", INC, "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
+        assert int(subprocess.run([exe], capture_output=True, check=True).stdout) == C.sizeof(ptss.RenderConfig)
+    finally:
+        if os.path.exists(exe):
+            os.remove(exe)
+    scene = ptss.Scene("cornell")
+    ctx = C.c_void_p()
+    cfg.width = cfg.height = 32
+    cfg.structSize -= 8   # what a caller compiled before the last two fields existed would pass
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
+    assert b"structSize" in L.ptss_last_error_detail()
+    cfg.structSize = 0    # a caller that zero-filled the struct itself
+    assert L.ptss_create(C.byref(scene.desc), C.byref(cfg), C.byref(ctx)) == -1
+    assert L.ptss_error_string(-6).decode().startswith("a frame lane timed out")
+
+
 def test_bad_scene_is_rejected_before_touching_the_gpu():
     L = ptss.device_lib()
     cfg = ptss.RenderConfig()

@@ -35,15 +35,26 @@ def run_bench(world, port, tmp_path, steps=2, warmup=1, extra=(), rehearsal=("--
 
 
 def test_ranks_print_one_contract_line_and_gather_the_unsharded_frame(tmp_path):
-    one, frame1 = run_bench(1, 29541, tmp_path, extra=["--no-cpu-baseline"])
-    two, frame2 = run_bench(2, 29542, tmp_path)
-    six, frame6 = run_bench(4, 29546, tmp_path)
+    # (S = 20 everywhere — the sample lanes own the random streams, so only runs of one S trace the same rays —: a 4-rank shard
+    # is then 10.4 M rays per pass, which the library gives two frame lanes, as it does an 8-rank shard at the default S)
+    s20 = ["--samples-per-pass", "20"]
+    one, frame1 = run_bench(1, 29541, tmp_path, extra=["--no-cpu-baseline"] + s20)
+    two, frame2 = run_bench(2, 29542, tmp_path, extra=s20)
+    six, frame6 = run_bench(4, 29546, tmp_path, extra=s20)
     for j, n in ((one, 1), (two, 2), (six, 4)):
         assert j["n_gpus"] == n and j["steps"] == 2 and j["warmup"] == 1
         assert j["unit"] == "Mrays/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
         assert j["value"] > 0 and j["ms_per_step"] > 0
-        assert j["roofline"]["bound"] in ("hbm", "valu") and 0 < j["roofline"]["frac"] < 1
+        # the roofline object is there at every N — also where a rank's shard is small enough for the library to give it two
+        # frame lanes (the 4-rank shards: the launch time is then the union of the lanes' launch intervals) — with the
+        # moved-bytes figure beside SURVEY §8(d)'s 152 B per ray-bounce and the PMC counters scaled to the shard
+        roof = j["roofline"]
+        assert roof["bound"] in ("hbm", "valu") and 0 < roof["frac"] < 1
+        assert 0 < roof["moved_bytes_frac"] < roof["frac"] and 100 < roof["moved_bytes_per_ray_bounce"] < 152
+        assert roof["traffic"] > 0 and roof["valu"]["issue_frac"] > 0 and roof["avg_launch_us"] > 0
         assert j["scaling"] == "strong" and "cpu_baseline" not in j
+        assert "2000 spp = BASELINE configs[2]'s 2000 spp" in j["metric"] and j["passes_per_step"] == 50   # 2 x 50 x S = 20
+    assert six["config"]["frame_lanes"] == 2 and "lanes_note" in six["roofline"] and one["config"]["frame_lanes"] == 1
     # Same seed, same passes: the shards together trace exactly the rays the single context traces ...
     assert two["ray_bounces"] == one["ray_bounces"] == six["ray_bounces"]
     # ... and the gathered, un-tiled accumulator is the single context's, element for element (1920x1080: far more than
@@ -51,6 +62,18 @@ def test_ranks_print_one_contract_line_and_gather_the_unsharded_frame(tmp_path):
     assert frame1.shape == frame2.shape == frame6.shape == (1920 * 1080, 3)
     assert np.array_equal(frame1.astype(np.int64), frame2.astype(np.int64))
     assert np.array_equal(frame1.astype(np.int64), frame6.astype(np.int64))
+
+
+def test_the_drivers_twenty_steps_render_the_configs_2000_spp(tmp_path):
+    """`bench.py --gpus 1 --steps 20 --warmup 5` is what the driver runs: 20 steps x 2 passes x S = 50 = BASELINE configs[2]'s
+    2000 spp, and the line says so; the roofline object is complete."""
+    j, _ = run_bench(1, 29571, tmp_path, steps=20, warmup=5, extra=["--no-cpu-baseline"], rehearsal=())
+    assert j["steps"] == 20 and j["warmup"] == 5 and j["passes_per_step"] == 2 and j["config"]["samples_per_pass"] == 50
+    assert "2000 spp = BASELINE configs[2]'s 2000 spp" in j["metric"]
+    roof = j["roofline"]
+    assert roof["launches"] == 20 * 2 * 8 and 0 < roof["moved_bytes_frac"] < roof["frac"] < 1
+    assert roof["traffic"] > 0 and "scaled by 1.25" in roof["traffic_source"]
+    assert j["ray_bounces"] > 2_000_000_000 * 5
 
 
 def test_rccl_itself_runs_the_collective_path_with_one_rank(tmp_path):
@@ -88,10 +111,10 @@ def test_config2_line_is_complete(tmp_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
-    assert j["config"]["name"] == "c2" and "1280x720" in j["config"]["workload"] and "96 spp" in j["metric"]
+    assert j["config"]["name"] == "c2" and "1280x720" in j["config"]["workload"] and "513 spp run" in j["metric"]
     roof = j["roofline"]
     assert roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and roof["bound"] in ("hbm", "valu")
     assert roof["traffic"] > 0 and "pmc_counters.json" in roof["traffic_source"]
     assert 0 < roof["valu"]["issue_frac"] < 1 and 0 < roof["valu"]["lanes_active"] <= 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1 and "1280x720" in j["cpu_baseline"]["sample"]
-    assert j["s1_mrays_per_s"] > 0 and j["s1_one_lane_mrays_per_s"] > 0
+    assert j["s1_mrays_per_s"] > 0 and j["s1_free_running_lanes_mrays_per_s"] > 0

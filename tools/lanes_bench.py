@@ -1,5 +1,6 @@
 """tools/lanes_bench.py [config=c3] [S=1] [passes=200] [width height] — whole-frame Mrays/s of one context with 1, 2, 3, 4 frame
-lanes (width/height override the config's frame: where does the automatic choice belong?)."""
+lanes, free-running (cfg.lanesFreeRun) and, for 2 lanes, ordered strictly on the caller's stream (width/height override the
+config's frame: where does the automatic choice belong?)."""
 import os
 import sys
 import time
@@ -17,9 +18,9 @@ if len(sys.argv) > 5:
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 scene = ptss.Scene(cfg["preset"])
-for lanes in (1, 2, 3, 4, 1, 2):
+for lanes, free in ((1, True), (2, True), (2, False), (3, True), (4, True), (1, True), (2, True), (2, False)):
     r = ptss.Renderer(scene, cfg["width"], cfg["height"], max_iterations=cfg["bounces"], sync_each_frame=False, samples_per_pass=S,
-                      frame_lanes=lanes)
+                      frame_lanes=lanes, lanes_free_run=free)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     pix = torch.zeros((r.local_pixels, 4), dtype=torch.uint8, device="cuda")
     for _ in range(max(3, passes // 10)):
@@ -32,6 +33,6 @@ for lanes in (1, 2, 3, 4, 1, 2):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rays = r.total_ray_bounces() - r0
-    print("%s %dx%d S=%d lanes=%d: %.4f ms per pass, %.1f Mrays/s, guard timeouts %d" % (sys.argv[1] if len(sys.argv) > 1 else "c3", cfg["width"], cfg["height"], S, lanes,
+    print("%s %dx%d S=%d lanes=%d %s: %.4f ms per pass, %.1f Mrays/s, guard timeouts %d" % (sys.argv[1] if len(sys.argv) > 1 else "c3", cfg["width"], cfg["height"], S, lanes, "free-running" if free else "strict",
           dt / passes * 1e3, rays / dt / 1e6, r.guard_timeouts()))
     r.close()

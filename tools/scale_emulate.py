@@ -16,7 +16,7 @@ scene = ptss.Scene("mixed")
 base = None
 for world in (1, 2, 4, 8):
     r = ptss.Renderer(scene, 1920, 1080, max_iterations=8, tile_rank=0, tile_world=world, band_rows=8, sync_each_frame=False,
-                      samples_per_pass=S, frame_lanes=LANES)
+                      samples_per_pass=S, frame_lanes=LANES, lanes_free_run=True)   # as bench.py creates its context
     for _ in range(30):
         r.generate_frame()
     r.synchronize()
