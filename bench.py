@@ -272,7 +272,7 @@ def main():
     if rank == 0 and dist is not None:   # untimed sanity: the gathered tiles tile the frame
         sizes = [len(ptss.tile_rows(H, BAND_ROWS, k, world)) * W for k in range(world)]
         frame = tiles.untile([g[:sizes[k]].cpu().numpy() for k, g in enumerate(gather_list)], W, H, BAND_ROWS)
-        assert frame.shape == (W * H, 3) and int(frame.max()) <= 255 * (steps + args.warmup) * samples
+        assert frame.shape == (W * H, 3) and int(frame.max()) <= 255 * (steps + args.warmup) * passes_per_step * samples
         if args.dump_frame:
             import numpy as np
             np.save(args.dump_frame, frame)

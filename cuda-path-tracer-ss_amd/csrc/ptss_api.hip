@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include "ptquant.h"
+#include "pttri.h"
 
 using namespace ptv;
 
@@ -91,7 +92,11 @@ struct ptss_context {
     uint32_t* dAccumOwned = nullptr;
     uint32_t* dAccum = nullptr;  // owned or bound
     float* dFsum = nullptr;
-    uint32_t* dStaged = nullptr;  // S > 1: per-stream sample words of the current pass
+    uint32_t* dStaged = nullptr;  // S > 1: per-stream sample words of the current pass. Free-running lanes: TWO buffers, by frame parity —
+                                  // the lanes of frame N + 1 already park samples while displayKernel of frame N (on the caller's stream,
+                                  // behind the join) still adds up frame N's; a lane starts frame N + 2 only behind displayKernel of frame N
+    bool stagedTwice = false;
+    hipEvent_t evDisplay[2] = {nullptr, nullptr};   // displayKernel of the last frame of each parity has run (stagedTwice only)
     uint32_t capacity = 0, numPixels = 0;  // capacity: stride of the per-pixel planes (rngHome)
     uint32_t samples = 1;                    // cfg.samplesPerPass (sample lanes per pixel)
     bool cameraDirty = true;           // primary-ray precomputes must be refreshed
@@ -228,7 +233,8 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offTriVert = off;     off += 2 * L.numTriangles;
     L.offMaterial = off;    off += 5 * L.numMaterials;
     L.offPointLight = off;  off += 2 * L.numPointLights;
-    L.offAreaLight = off;   off += L.numAreaLights;
+    L.offAreaLight = off;   off += 2 * L.numAreaLights;
+    L.offTriPos = off;      off += (L.numTriangles + 3) / 4;   // ints: stored position of each original triangle index
     L.offQuant = off;       off += ptq::kTableFloats / 4;
     L.offPrimSphere = off;  off += accel ? 0 : sphereAlloc;  // the chunked traversal has no camera-origin shortcut
     L.offPrimTri = off;     off += 2 * L.numTriangles;
@@ -264,6 +270,20 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         const double n2 = std::sqrt((double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z);
         if (!(n1 * n2 <= 0x1p100)) L.triDetBounded = 0;  // false for NaN / infinite edges as well
     }
+    // Storage order of the triangles: the caller's, or — SceneLayout::triClassed — grouped by edge class (pttri.h), the caller's
+    // order kept inside a group. triOrder[position] = original index.
+    L.triClassed = (L.triDetBounded && L.sphereBounded) ? 1 : 0;
+    std::vector<int> triOrder((size_t)L.numTriangles), triCode((size_t)L.numTriangles, 0);
+    for (int i = 0; i < L.numTriangles; ++i) {
+        triOrder[(size_t)i] = i;
+        const ptss_triangle& t = s.triangles[i];
+        if (L.triClassed) triCode[(size_t)i] = pttri::triangleClass(t.vertex1 - t.vertex0, t.vertex2 - t.vertex0);   // the edges as stored below
+    }
+    std::stable_sort(triOrder.begin(), triOrder.end(), [&](int a, int b) { return triCode[(size_t)a] < triCode[(size_t)b]; });
+    for (int code = 0, pos = 0; code <= 16; ++code) {
+        while (pos < L.numTriangles && triCode[(size_t)triOrder[(size_t)pos]] < code) ++pos;
+        L.triClassBegin[code] = pos;
+    }
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
     ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));
     std::vector<int> order;
@@ -298,18 +318,20 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         const double infl = Rmax * Rmax * (1 + kAccelM) * (1 + kAccelM) * (1 + kAccelM) * (1 + 1e-9);
         blob[L.offChunk + k] = float4{Cf[0], Cf[1], Cf[2], std::nextafter((float)infl, INFINITY)};
     }
-    for (int i = 0; i < L.numTriangles; ++i) {
+    for (int pos = 0; pos < L.numTriangles; ++pos) {
+        const int i = triOrder[(size_t)pos];
         const ptss_triangle& t = s.triangles[i];
         const vec3 e1 = t.vertex1 - t.vertex0;  // Primitives.h:34-35, hoisted (same subtraction, same bits)
         const vec3 e2 = t.vertex2 - t.vertex0;
-        blob[L.offTri + 3 * i + 0] = float4{t.vertex0.x, t.vertex0.y, t.vertex0.z, u2f((uint32_t)t.materialIdx)};
-        blob[L.offTri + 3 * i + 1] = float4{e1.x, e1.y, e1.z, 0};
-        blob[L.offTri + 3 * i + 2] = float4{e2.x, e2.y, e2.z, 0};
-        blob[L.offTriNormal + 3 * i + 0] = float4{t.normal0.x, t.normal0.y, t.normal0.z, 0};
-        blob[L.offTriNormal + 3 * i + 1] = float4{t.normal1.x, t.normal1.y, t.normal1.z, 0};
-        blob[L.offTriNormal + 3 * i + 2] = float4{t.normal2.x, t.normal2.y, t.normal2.z, 0};
-        blob[L.offTriVert + 2 * i + 0] = float4{t.vertex1.x, t.vertex1.y, t.vertex1.z, 0};
-        blob[L.offTriVert + 2 * i + 1] = float4{t.vertex2.x, t.vertex2.y, t.vertex2.z, 0};
+        blob[L.offTri + 3 * pos + 0] = float4{t.vertex0.x, t.vertex0.y, t.vertex0.z, u2f((uint32_t)t.materialIdx)};
+        blob[L.offTri + 3 * pos + 1] = float4{e1.x, e1.y, e1.z, u2f(0xfffffffeu - (uint32_t)i)};   // the low half of the closest hit's (distance, 0xFFFFFFFE - original index) key
+        blob[L.offTri + 3 * pos + 2] = float4{e2.x, e2.y, e2.z, 0};
+        blob[L.offTriNormal + 3 * pos + 0] = float4{t.normal0.x, t.normal0.y, t.normal0.z, 0};
+        blob[L.offTriNormal + 3 * pos + 1] = float4{t.normal1.x, t.normal1.y, t.normal1.z, 0};
+        blob[L.offTriNormal + 3 * pos + 2] = float4{t.normal2.x, t.normal2.y, t.normal2.z, 0};
+        blob[L.offTriVert + 2 * pos + 0] = float4{t.vertex1.x, t.vertex1.y, t.vertex1.z, 0};
+        blob[L.offTriVert + 2 * pos + 1] = float4{t.vertex2.x, t.vertex2.y, t.vertex2.z, 0};
+        reinterpret_cast<int*>(&blob[L.offTriPos])[i] = pos;
     }
     for (int i = 0; i < L.numMaterials; ++i) {
         const ptss_material& m = s.materials[i];
@@ -327,7 +349,10 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     }
     for (int i = 0; i < L.numAreaLights; ++i) {
         const ptss_area_light& a = s.areaLights[i];
-        blob[L.offAreaLight + i] = float4{a.power.x, a.power.y, a.power.z, u2f((uint32_t)a.triangleIdx)};
+        // getAreaLightPoint picks triangle triangleIdx or triangleIdx + 1 (CudaTracer.cu:408): both as stored positions
+        const int* triPos = reinterpret_cast<const int*>(&blob[L.offTriPos]);
+        blob[L.offAreaLight + 2 * i] = float4{a.power.x, a.power.y, a.power.z, u2f((uint32_t)triPos[a.triangleIdx])};
+        blob[L.offAreaLight + 2 * i + 1] = float4{u2f((uint32_t)triPos[a.triangleIdx + 1]), 0, 0, 0};
     }
 }
 
@@ -361,7 +386,7 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4*
     fb.guardTimeouts = reinterpret_cast<uint32_t*>(c->dTotal + ptss::kMaxLanes + 8);
     fb.accum = c->dAccum;
     fb.fsum = c->dFsum;
-    fb.staged = c->dStaged;
+    fb.staged = c->dStaged ? c->dStaged + (c->stagedTwice ? (size_t)(c->frameIndex & 1u) * c->capacity * c->samples : 0) : nullptr;
     fb.quantTable = reinterpret_cast<const float*>(c->dScene + c->layout.offQuant);
     fb.pixels = pixels;
     fb.regionCap = ln.regionCap;
@@ -635,8 +660,12 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(hipMemset(c->dFsum, 0, (size_t)3 * c->capacity * c->samples * sizeof(float)));
     }
     if (c->samples > 1) {
-        CREATE_TRY(hipMalloc(&c->dStaged, (size_t)c->capacity * c->samples * sizeof(uint32_t)));
-        CREATE_TRY(hipMemset(c->dStaged, 0, (size_t)c->capacity * c->samples * sizeof(uint32_t)));
+        c->stagedTwice = numLanes > 1 && cfg->lanesFreeRun != 0;
+        const size_t words = (size_t)c->capacity * c->samples * (c->stagedTwice ? 2 : 1);
+        CREATE_TRY(hipMalloc(&c->dStaged, words * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(c->dStaged, 0, words * sizeof(uint32_t)));
+        if (c->stagedTwice)
+            for (int q = 0; q < 2; ++q) CREATE_TRY(hipEventCreateWithFlags(&c->evDisplay[q], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreate(&c->evStart));
     CREATE_TRY(hipEventCreate(&c->evStop));
@@ -711,6 +740,8 @@ int ptss_destroy(ptss_context* c) {
         (void)hipFree(ln.dLastCounts);
     }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
+    for (int q = 0; q < 2; ++q)
+        if (c->evDisplay[q]) (void)hipEventDestroy(c->evDisplay[q]);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->evEpoch) (void)hipEventDestroy(c->evEpoch);
@@ -807,6 +838,11 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
         HIP_TRY(hipEventRecord(c->evFork, st));
         for (Lane& ln : c->lanes) HIP_TRY(hipStreamWaitEvent(ln.stream, c->evFork, 0));
     }
+    // Free-running lanes with S > 1: this frame parks its samples in the buffer of its parity, which displayKernel of the frame
+    // two back (same parity, on the caller's stream) must have emptied — the only thing a free-running lane ever waits for
+    // on the caller's side, and an event that has nearly always fired by now.
+    if (c->stagedTwice && c->frameIndex >= 2)
+        for (Lane& ln : c->lanes) HIP_TRY(hipStreamWaitEvent(ln.stream, c->evDisplay[c->frameIndex & 1u], 0));
     if (c->cfg.timeKernels) drainKernelEvents(c, false);
     // the shorter sphere candidate test: bounded geometry AND a camera within the same range (ray origins are the camera or points on primitives)
     const bool bounded = c->layout.sphereBounded != 0 && cameraInRange(c->camera);
@@ -881,7 +917,10 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             HIP_TRY(hipStreamWaitEvent(st, ln.evDone[c->frameIndex & 1u], 0));
         }
     }
-    if (c->samples > 1) HIP_TRY(ptss::launchDisplay(st, fbs[0]));  // S > 1: add the pass's staged samples, then the display value
+    if (c->samples > 1) {
+        HIP_TRY(ptss::launchDisplay(st, fbs[0]));  // S > 1: add the pass's staged samples, then the display value
+        if (c->stagedTwice) HIP_TRY(hipEventRecord(c->evDisplay[c->frameIndex & 1u], st));
+    }
     c->countParity ^= 1;
     c->frameIndex++;
 

@@ -82,13 +82,13 @@ struct SceneLayout {
     int offSphere;      // S x {cx, cy, cz, radius^2}; with accelSpheres: the spheres in spatially sorted order, padded to whole
                         // chunks of kChunkSpheres with copies of the last one
     int offSphereMat;   // ceil(S/4) x 4 ints
-    int offTri;         // T x 3: {v0.xyz, bits(materialIdx)}, {e1.xyz, 0}, {e2.xyz, 0}
+    int offTri;         // T x 3: {v0.xyz, bits(materialIdx)}, {e1.xyz, bits(0xFFFFFFFE - original index)}, {e2.xyz, 0} — in storage order (triClassed)
     int offTriNormal;   // T x 3: {n0,0},{n1,0},{n2,0}
     int offTriVert;     // T x 2: {v1,0},{v2,0}   (area-light sampling)
     int offMaterial;    // M x 5: {diffuseColor, diffAvg},{specularColor, specAvg},{absorption, refrAvg},
                         //        {emmitance, roughness},{specularExponent, indexOfRefraction, bits(flags), 0}
     int offPointLight;  // P x 2: {position,0},{power,0}
-    int offAreaLight;   // A x 1: {power, bits(triangleIdx)}
+    int offAreaLight;   // A x 2: {power, bits(position of triangle triangleIdx)}, {bits(position of triangleIdx + 1), 0, 0, 0}
     // Sphere acceleration (scenes with many spheres; packScene decides): chunks of kChunkSpheres consecutive sorted spheres
     // with a conservative bounding sphere each; a lane visits only the chunks its ray can touch (ptss_kernels.hip).
     int accelSpheres;   // 0: every sphere is tested by every ray (the reference's loop); 1: chunked
@@ -111,6 +111,13 @@ struct SceneLayout {
                         //    hold one segment and they do not: -1.4 % on configs[2]'s
     int triDetBounded;  // 1: every triangle has |e1| |e2| <= 2^100 (finite), so |det| = |e1 . (d x e2)| < 2^126 whenever
                         //    |d|^2 < 2^30 — the closest-hit triangle loop may then use the reciprocal's fast path unguarded
+    int triClassed;     // 1: every vertex is finite (bounded geometry) and the triangles are STORED GROUPED BY EDGE CLASS (pttri.h; the
+                        //    caller's order inside a group): the uniform triangle loops run one loop per class, each with the body that
+                        //    leaves out the products with that class's exact-zero edge components; the closest hit decides by the key
+                        //    (distance, ~original index), which is what the reference's sequential `dist <= distance` rule ends on.
+                        //    0: the caller's order, the general body, the sequential rule
+    int triClassBegin[17];  // positions [triClassBegin[c], triClassBegin[c + 1]) hold the triangles of class code c = class(e1) * 4 + class(e2)
+    int offTriPos;      // ints: stored position of each original triangle index
 };
 
 struct TileMap {

@@ -25,6 +25,7 @@
 // every restructuring below is argued exact where it is made.
 #include "ptss_device.h"
 #include "ptquant.h"
+#include "pttri.h"
 
 using namespace ptv;
 
@@ -226,8 +227,8 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
     return h;
 }
 
-// ---- The closest hit's triangle loop, lean form (triangleTest stays for the any-hit loops and as the
-// fallback). Same operations on the same values as triangleTest for every lane whose result is used; what changes:
+// ---- The closest hit's triangle loop, lean form (triangleTest stays for the any-hit loops and as the fallback). Same
+// operations on the same values as triangleTest for every lane whose result is used; what changes:
 //   * The reciprocal's range guard moves out of the loop: |det| = |e1 . (d x e2)| <= |e1| |e2| |d| (1 + 4 ulp); the host
 //     bounds |e1| |e2| <= 2^100 (SceneLayout::triDetBounded) and the caller tests |d|^2 < 2^30 once per query, so
 //     |det| < 2^126; below, results with |det| <= 1e-7 are discarded (Primitives.h:41) — exactly the operand range on which
@@ -241,43 +242,86 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
 //     neighbouring pixels — and then whole waves do reject a triangle early. (No exit at all is the faster loop on
 //     incoherent rays, tools/microbench/loops.hip: 157 -> 138 SIMD-cycles per triangle per wave, and the slower kernel:
 //     same-box A/B -1.6 %.)
+//   * EDGE CLASSES (kC1, kC2; pttri.h). A triangle whose edges run along coordinate axes (every wall and light panel of the
+//     presets but two) loses the products with the exact zeros: 13 instead of 25 operations up to the distance test with two
+//     such edges, 19 with one. Every lane of the wave tests the SAME triangle, so the body could be chosen per triangle
+//     without divergence — but a scalar branch tree per triangle (35 scalar instructions, 9 branches) cost more than the
+//     shorter bodies saved (same-box A/B -2.5 %: scalar instructions are not free beside vector ones,
+//     tools/microbench/vgpr_banks.hip). So the host stores the triangles GROUPED BY CLASS (SceneLayout::triClassed /
+//     triClassBegin) and the loop becomes one loop per class: no dispatch at all. The visiting order is then no longer the
+//     caller's, which matters where the reference's sequential rule `dist <= distance` (Primitives.h:52) decides between two
+//     triangles hit at exactly the same distance: it ends on the HIGHEST index among them. kKeyed keeps (distance,
+//     0xFFFFFFFE - original index) as one 64-bit key — distances that pass `dist > 0` order like their bit patterns — and
+//     accepts a hit iff its key is SMALLER than the kept one: minimum distance, then highest original index; the initial key
+//     (sphere distance, 0xFFFFFFFF) lets a triangle at exactly the sphere's distance win, as `<=` does. One v_cmp_lt_u64 in
+//     place of one v_cmp_ngt_f32: the same issue cost. Exactness of the class forms, preconditions and the one case the
+//     caller re-evaluates (a kept weight of exactly zero): pttri.h.
 struct TriBest {
-    float dist;  // the running `distance` (Primitives.h:52), shared with the sphere phase
-    int idx;     // -1: no triangle accepted
+    float dist;    // the running `distance` (Primitives.h:52), shared with the sphere phase
+    uint32_t key;  // 0xFFFFFFFF: no triangle accepted; kKeyed: 0xFFFFFFFE - original index; else the triangle's index
     float w1, w2;
 };
-template <bool kPrimary>
-__device__ __forceinline__ void triangleHybrid(const TriRows& tr, float4 ps, float4 pr, int i, vec3 o, vec3 d, unsigned long long liveMask,
-                                               TriBest& best) {
-    const vec3 e1 = xyz(tr.b), e2 = xyz(tr.c);
-    const vec3 q = cross(d, e2);
-    const float det = dot(e1, q);
-    const float inverseDet = ptm::rcp_in_range(det);
-    vec3 s, r;
-    float e2r;
-    if constexpr (kPrimary) {
-        s = xyz(ps);
-        r = xyz(pr);
-        e2r = ps.w;
+constexpr uint32_t kNoTriangle = 0xffffffffu;
+template <bool kPrimary, int kC1, int kC2, bool kKeyed>
+__device__ __forceinline__ void triangleClassed(const float4* rows /* {v0, mat}, {e1, key}, {e2} */, const float4* prim /* {s, e2 . r}, {r} */,
+                                                uint32_t index, vec3 o, vec3 d, unsigned long long liveMask, TriBest& best) {
+    vec3 v0 = v3(0, 0, 0), ps = v3(0, 0, 0), pr = v3(0, 0, 0);
+    float pe2r = 0;
+    if constexpr (kPrimary) {   // the camera-origin test never looks at v0
+        const float4 a = prim[0];
+        ps = xyz(a);
+        pe2r = a.w;
+        pr = xyz(loadRow16(prim + 1));
     } else {
-        s = o - xyz(tr.a);
-        r = cross(s, e1);
-        e2r = dot(e2, r);
+        v0 = xyz(loadRow16(rows));
     }
-    const float dist = e2r * inverseDet;
-    const unsigned long long passMask = liveMask & maskOf(!(ptm::abs(det) <= 1e-7f)) & maskOf(!(dist <= 0.0f)) & maskOf(!(dist > best.dist));
+    const float4 rowE1 = rows[1];
+    const pttri::Head h = pttri::head<kC1, kC2, kPrimary>(v0, xyz(rowE1), xyz(loadRow16(rows + 2)), ps, pr, pe2r, o, d);
+    const uint32_t key = kKeyed ? asU(rowE1.w) : index;
+    unsigned long long passMask = liveMask & maskOf(!(ptm::abs(h.det) <= 1e-7f)) & maskOf(!(h.dist <= 0.0f));
+    if constexpr (kKeyed) {
+        const unsigned long long mine = ((unsigned long long)asU(h.dist) << 32) | key, kept = ((unsigned long long)asU(best.dist) << 32) | best.key;
+        passMask &= maskOf(mine < kept);
+    } else {
+        passMask &= maskOf(!(h.dist > best.dist));
+    }
     if (passMask != 0ull) {
-        const float b1 = dot(s, q) * inverseDet;
-        const float b2 = dot(d, r) * inverseDet;
-        const float b0 = 1.0f - (b1 + b2);
+        float b0, b1, b2;
+        pttri::weights<kC1, kC2>(h, d, b0, b1, b2);
         const unsigned long long hitMask = passMask & maskOf(!(__builtin_fminf(__builtin_fminf(b0, b1), b2) < 0));
         const bool hit = __builtin_amdgcn_inverse_ballot_w64(hitMask);
-        best.dist = hit ? dist : best.dist;
-        best.idx = hit ? i : best.idx;
+        best.dist = hit ? h.dist : best.dist;
+        best.key = hit ? key : best.key;
         best.w1 = hit ? b1 : best.w1;
         best.w2 = hit ? b2 : best.w2;
     }
 }
+// One loop per edge class over the triangles stored for it (SceneLayout::triClassBegin); BODY(c1, c2, t) tests stored triangle t
+#define PTSS_FOR_TRIANGLES_BY_CLASS(L, BODY)                                                                        \
+    do {                                                                                                            \
+        PTSS_TRI_CLASS_LOOP(L, 0, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 2, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 3, BODY) \
+        PTSS_TRI_CLASS_LOOP(L, 1, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 1, 2, BODY) PTSS_TRI_CLASS_LOOP(L, 1, 3, BODY)      \
+        PTSS_TRI_CLASS_LOOP(L, 2, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 2, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 2, 3, BODY)      \
+        PTSS_TRI_CLASS_LOOP(L, 3, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 3, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 3, 2, BODY)      \
+    } while (0)
+#define PTSS_TRI_CLASS_LOOP(L, c1, c2, BODY) \
+    for (int t = (L).triClassBegin[(c1) * 4 + (c2)]; t < (L).triClassBegin[(c1) * 4 + (c2) + 1]; ++t) { BODY(c1, c2, t) }
+
+// the any-hit form of the same bodies (lineOfSight is an OR over independent tests: any order)
+template <int kC1, int kC2>
+__device__ __forceinline__ void triangleClassedAny(const float4* rows, vec3 o, vec3 d, float limit, unsigned long long& need, unsigned long long& blocked) {
+    const pttri::Head h = pttri::head<kC1, kC2, false>(xyz(loadRow16(rows)), xyz(loadRow16(rows + 1)), xyz(loadRow16(rows + 2)), v3(0, 0, 0), v3(0, 0, 0), 0.0f, o, d);
+    const unsigned long long passMask = need & maskOf(!(ptm::abs(h.det) <= 1e-7f)) & maskOf(!(h.dist <= 0.0f)) & maskOf(!(h.dist > limit));
+    if (passMask != 0ull) {
+        float b0, b1, b2;
+        pttri::weights<kC1, kC2>(h, d, b0, b1, b2);
+        const unsigned long long hitMask = passMask & maskOf(!(__builtin_fminf(__builtin_fminf(b0, b1), b2) < 0));
+        blocked |= hitMask;
+        need &= ~hitMask;
+    }
+}
+// what the class bodies need of a query (pttri.h): a finite direction short enough to bound |det|, a finite origin
+__device__ __forceinline__ bool classedQueryOk(vec3 o, vec3 d) { return waveAll(dot(d, d) < 0x1p30f) && waveAll(dot(o, o) < 0x1p100f); }
 // ---- Primary (bounce 0) variants. Every eye ray starts at camera.position, so whatever the tests
 // compute from the ORIGIN and the primitive alone is the same for all lanes and all pixels of a frame:
 //   sphere:   v = o - centre,  c = dot(v,v) - r^2                    (Primitives.h:109,113)
@@ -775,19 +819,6 @@ __device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLa
 }
 
 // the triangle half of lineOfSight alone (the sphere half having been answered by anySpheresHybrid)
-__device__ __forceinline__ bool anyTriangles(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, bool live) {
-    unsigned long long need = maskOf(live);
-    unsigned long long hitMask = 0ull;
-    for (int i = 0; i < L.numTriangles; ++i) {
-        if (need == 0ull) break;
-        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
-        const TriHit th = triangleTest(tcur, lo, w_i, distance, need);
-        hitMask |= th.hitMask;
-        need &= ~th.hitMask;
-    }
-    return __builtin_amdgcn_inverse_ballot_w64(hitMask);
-}
-
 template <bool kPrimary, bool kAccel, bool kBounded>
 __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d, bool live, uint32_t* ws) {
     Hit h;
@@ -815,29 +846,63 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
         }
     }
     const unsigned long long liveMask = maskOf(live);
-    // one test per query instead of one per triangle: |d|^2 < 2^30 in every lane (false for a NaN direction)
-    if (L.triDetBounded && waveAll(dot(d, d) < 0x1p30f)) {
-        TriBest best{h.distance, -1, 0.0f, 0.0f};
-        for (int i = 0; i < L.numTriangles; ++i) {
-            const TriRows tcur = kPrimary ? loadTriEdges(sc + L.offTri + 3 * i) : loadTri(sc + L.offTri + 3 * i);
-            float4 ps = float4{0, 0, 0, 0}, pr = ps;
-            if constexpr (kPrimary) {
-                ps = sc[L.offPrimTri + 2 * i];
-                pr = loadRow16(sc + L.offPrimTri + 2 * i + 1);
+    if (L.triClassed) {
+        // The triangles are stored grouped by edge class. One test per query (not per triangle) admits the class bodies:
+        // |d|^2 < 2^30 bounds |det| below the reciprocal's fast range, and with a finite origin every product the class
+        // forms leave out is an exact zero (pttri.h). A wave that fails it (a NaN or enormous ray) walks the triangles in the
+        // CALLER's order with the guarded general test below: the reference's sequential rule, NaNs included.
+        if (classedQueryOk(o, d)) {
+            TriBest best{h.distance, kNoTriangle, 0.0f, 0.0f};
+#define PTSS_CLOSEST_BODY(c1, c2, t) \
+    triangleClassed<kPrimary, c1, c2, true>(sc + L.offTri + 3 * t, sc + L.offPrimTri + 2 * t, 0u, o, d, liveMask, best);
+            PTSS_FOR_TRIANGLES_BY_CLASS(L, PTSS_CLOSEST_BODY);
+#undef PTSS_CLOSEST_BODY
+            if (waveAny(best.key != kNoTriangle)) {
+                const int* posOf = reinterpret_cast<const int*>(sc + L.offTriPos);
+                int pos = 0;
+                if (best.key != kNoTriangle) pos = posOf[0xfffffffeu - best.key];   // per-lane gather
+                // A kept weight that is exactly zero (the hit lies on an edge of the triangle) may carry the other sign in a
+                // class form (pttri.h): those lanes — hardly ever one — take the general form's weights, so that even the sign
+                // of a zero normal component is the reference's. The general form accepts the same hit at the same distance.
+                const bool zeroWeight = best.key != kNoTriangle && (best.w1 == 0.0f || best.w2 == 0.0f);
+                if (waveAny(zeroWeight)) {
+                    if (zeroWeight) {
+                        const float4* rows = sc + L.offTri + 3 * pos;   // per-lane gathers
+                        const float4* prim = sc + L.offPrimTri + 2 * pos;
+                        const pttri::Head g = pttri::head<0, 0, kPrimary>(xyz(rows[0]), xyz(rows[1]), xyz(rows[2]), xyz(prim[0]), xyz(prim[1]), prim[0].w, o, d);
+                        float b0;
+                        pttri::weights<0, 0>(g, d, b0, best.w1, best.w2);
+                    }
+                }
+                if (best.key != kNoTriangle) {
+                    h.distance = best.dist;
+                    h.kind = 2;
+                    h.idx = pos;
+                    h.w1 = best.w1;
+                    h.w2 = best.w2;
+                    h.w0 = 1.0f - (best.w1 + best.w2);  // Primitives.h:64, from the kept pair
+                }
             }
-            triangleHybrid<kPrimary>(tcur, ps, pr, i, o, d, liveMask, best);
+            return h;
         }
-        if (best.idx >= 0) {
+    } else if (L.triDetBounded && waveAll(dot(d, d) < 0x1p30f)) {
+        // the caller's order, the general body, the sequential rule; the reciprocal's range guard proven once per query
+        TriBest best{h.distance, kNoTriangle, 0.0f, 0.0f};
+        for (int i = 0; i < L.numTriangles; ++i)
+            triangleClassed<kPrimary, 0, 0, false>(sc + L.offTri + 3 * i, sc + L.offPrimTri + 2 * i, (uint32_t)i, o, d, liveMask, best);
+        if (best.key != kNoTriangle) {
             h.distance = best.dist;
             h.kind = 2;
-            h.idx = best.idx;
+            h.idx = (int)best.key;
             h.w1 = best.w1;
             h.w2 = best.w2;
             h.w0 = 1.0f - (best.w1 + best.w2);  // Primitives.h:64, from the kept pair
         }
         return h;
     }
-    for (int i = 0; i < L.numTriangles; ++i) {   // the guarded loop: unbounded edges, or a direction of enormous length
+    const int* posOfOriginal = reinterpret_cast<const int*>(sc + L.offTriPos);
+    for (int k = 0; k < L.numTriangles; ++k) {   // the guarded loop, in the caller's order: unbounded edges, or a ray of enormous length
+        const int i = L.triClassed ? posOfOriginal[k] : k;   // where original triangle k is stored
         const TriRows tcur = kPrimary ? loadTriEdges(sc + L.offTri + 3 * i) : loadTri(sc + L.offTri + 3 * i);
         const TriHit th = kPrimary ? triangleTestPrimary(tcur, sc[L.offPrimTri + 2 * i], loadRow16(sc + L.offPrimTri + 2 * i + 1), d,
                                                          h.distance, liveMask)
@@ -852,6 +917,35 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
         }
     }
     return h;
+}
+
+// the triangle half of lineOfSight for a wave whose lanes all test the same triangle at a time: `need` = lanes that still want an
+// answer, `blocked` collects the verdicts. Grouped storage (SceneLayout::triClassed): one loop per edge class with its shorter
+// body, the reciprocal's guard proven once per pass; otherwise, and for non-finite or enormous segments, the guarded general test.
+__device__ __forceinline__ void anyTriangleLoop(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, unsigned long long& need,
+                                                unsigned long long& blocked) {
+    if (L.triClassed && classedQueryOk(lo, w_i)) {
+#define PTSS_ANY_BODY(c1, c2, t)   \
+    if (need == 0ull) break;      \
+    triangleClassedAny<c1, c2>(sc + L.offTri + 3 * t, lo, w_i, distance, need, blocked);
+        PTSS_FOR_TRIANGLES_BY_CLASS(L, PTSS_ANY_BODY);
+#undef PTSS_ANY_BODY
+        return;
+    }
+    for (int i = 0; i < L.numTriangles; ++i) {
+        if (need == 0ull) break;
+        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
+        const TriHit th = triangleTest(tcur, lo, w_i, distance, need);
+        blocked |= th.hitMask;
+        need &= ~th.hitMask;
+    }
+}
+
+// the triangle half of lineOfSight alone (the sphere half having been answered by anySpheresHybrid)
+__device__ __forceinline__ bool anyTriangles(const float4* sc, const SceneLayout& L, vec3 lo, vec3 w_i, float distance, bool live) {
+    unsigned long long need = maskOf(live), blocked = 0ull;
+    anyTriangleLoop(sc, L, lo, w_i, distance, need, blocked);
+    return __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
 // ---- the any-hit loops of lineOfSight, CudaTracer.cu:437-452: true when some primitive blocks the
@@ -879,13 +973,7 @@ __device__ __forceinline__ bool anyHit(const float4* sc, const SceneLayout& L, v
     }
     unsigned long long need = maskOf(live) & ~maskOf(occluded);  // lanes that still want an answer
     unsigned long long blocked = 0ull;
-    for (int i = 0; i < L.numTriangles; ++i) {
-        if (need == 0ull) break;
-        const TriRows tcur = loadTri(sc + L.offTri + 3 * i);
-        const TriHit th = triangleTest(tcur, lo, w_i, distance, need);
-        blocked |= th.hitMask;
-        need &= ~th.hitMask;
-    }
+    anyTriangleLoop(sc, L, lo, w_i, distance, need, blocked);
     return occluded || __builtin_amdgcn_inverse_ballot_w64(blocked);
 }
 
@@ -1270,8 +1358,11 @@ __device__ __forceinline__ void finishPath(const FrameBuffers& fb, const RayRegs
 constexpr unsigned long long kPeerWaitTicks = 200000000ull;
 __device__ __forceinline__ bool peerWaitExpired(unsigned long long& since) {
     const unsigned long long now = wall_clock64();
-    if (since == 0ull) since = now | 1ull;
-    return now - since > kPeerWaitTicks;
+    if (since == 0ull) {   // the first unsuccessful poll starts the clock
+        since = now | 1ull;
+        return false;
+    }
+    return now > since && now - since > kPeerWaitTicks;
 }
 
 __device__ __forceinline__ uint32_t frameLiveCount(const FrameBuffers& fb, int bounce, uint32_t own, const uint32_t* target) {
@@ -1558,13 +1649,14 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                     if (li < L.numPointLights) {
                         lightPoint = xyz(loadRow16(sc + L.offPointLight + 2 * li));
                     } else {  // getAreaLightPoint :392-418 — four draws whether or not the light ends up visible
-                        const float4 light = sc[L.offAreaLight + (li - L.numPointLights)];
+                        const float4 light = sc[L.offAreaLight + 2 * (li - L.numPointLights)];
                         const float u1 = ptrng::uniform(ray.rng);
                         const float u2 = ptrng::uniform(ray.rng);
                         const float u3 = ptrng::uniform(ray.rng);
                         const float inverseTotal = ptm::rcp(u1 + u2 + u3);  // 1 / (u1+u2+u3), :403
                         const float weight0 = u1 * inverseTotal, weight1 = u2 * inverseTotal, weight2 = u3 * inverseTotal;
-                        const int tri = (int)asU(light.w) + ((ptrng::uniform(ray.rng) > .5f) ? 0 : 1);
+                        // triangleIdx or triangleIdx + 1, :408 — as stored positions (the triangles may be stored grouped by class)
+                        const int tri = (ptrng::uniform(ray.rng) > .5f) ? (int)asU(light.w) : (int)asU(sc[L.offAreaLight + 2 * (li - L.numPointLights) + 1].x);
                         const vec3 a = xyz(loadRow16(sc + L.offTri + 3 * tri));
                         const vec3 b = xyz(loadRow16(sc + L.offTriVert + 2 * tri));
                         const vec3 c = xyz(loadRow16(sc + L.offTriVert + 2 * tri + 1));
@@ -1701,7 +1793,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 if (li >= numLights) continue;
                 if (need[k] && wqAnswer[k * 64 + lane] == 0) {
                     const vec3 power = (li < L.numPointLights) ? xyz(loadRow16(sc + L.offPointLight + 2 * li + 1))
-                                                               : xyz(loadRow16(sc + L.offAreaLight + (li - L.numPointLights)));
+                                                               : xyz(loadRow16(sc + L.offAreaLight + 2 * (li - L.numPointLights)));
                     addLambertTerm(radiance, cosL[k], power, distance2[k], mat[0]);
                 }
             }

@@ -9,11 +9,39 @@
 #include "HostOps.h"
 #include "Scene.h"
 #include "ptquant.h"
+#include "pttri.h"
 #include "xorwow.h"
 
 struct ptss_scene {
     Scene scene;
 };
+
+// Triangle::intersectRay (Primitives.h:25-83) for n (triangle, ray) pairs in the general form and in the edge-class form
+// the kernels pick for that triangle (csrc/pttri.h — the very functions the kernels call, compiled for the host).
+namespace {
+using namespace ptv;
+template <int kC1, int kC2>
+void triangleForm(const float* t, const float* o3, const float* d3, float limit, bool primary, float* out) {
+    const vec3 v0 = v3(t[0], t[1], t[2]), e1 = v3(t[3], t[4], t[5]), e2 = v3(t[6], t[7], t[8]);
+    const vec3 o = v3(o3[0], o3[1], o3[2]), d = v3(d3[0], d3[1], d3[2]);
+    pttri::Head h;
+    if (primary) {   // what primaryPrepKernel stores, with the general form
+        const vec3 s = o - v0, r = cross(s, e1);
+        h = pttri::head<kC1, kC2, true>(v0, e1, e2, s, r, dot(e2, r), o, d);
+    } else {
+        h = pttri::head<kC1, kC2, false>(v0, e1, e2, v3(0, 0, 0), v3(0, 0, 0), 0.0f, o, d);
+    }
+    float b0 = 0, b1 = 0, b2 = 0;
+    const bool pass = pttri::passesHead(h, limit);
+    if (pass) pttri::weights<kC1, kC2>(h, d, b0, b1, b2);
+    out[0] = (pass && pttri::passesWeights(b0, b1, b2)) ? 1.0f : 0.0f;
+    out[1] = h.dist;
+    out[2] = b0;
+    out[3] = b1;
+    out[4] = b2;
+    out[5] = h.det;
+}
+}  // namespace
 
 extern "C" {
 
@@ -83,6 +111,29 @@ int ptss_probe_math(int op, const float* x, const float* y, float* out, size_t n
             case 6: if (!y) return PTSS_HOST_EINVAL; out[i] = ptm::pow(x[i], y[i]); break;
             case 7: out[i] = ptm::sqrt(x[i]); break;
             default: return PTSS_HOST_EINVAL;
+        }
+    }
+    return PTSS_HOST_OK;
+}
+
+int ptss_probe_triangle_forms(const float* tri9, const float* o3, const float* d3, const float* limit, int primary, size_t n, int* cls,
+                              float* general6, float* classed6) {
+    if (!tri9 || !o3 || !d3 || !limit || !cls || !general6 || !classed6) return PTSS_HOST_EINVAL;
+    for (size_t i = 0; i < n; ++i) {
+        const float* t = tri9 + 9 * i;
+        const int c = pttri::triangleClass(v3(t[3], t[4], t[5]), v3(t[6], t[7], t[8]));
+        cls[i] = c;
+        triangleForm<0, 0>(t, o3 + 3 * i, d3 + 3 * i, limit[i], primary != 0, general6 + 6 * i);
+        float* out = classed6 + 6 * i;
+        switch (c) {
+#define PTSS_TRI_CASE(c1, c2) \
+    case (c1) * 4 + (c2): triangleForm<c1, c2>(t, o3 + 3 * i, d3 + 3 * i, limit[i], primary != 0, out); break;
+            PTSS_TRI_CASE(0, 1) PTSS_TRI_CASE(0, 2) PTSS_TRI_CASE(0, 3)
+            PTSS_TRI_CASE(1, 0) PTSS_TRI_CASE(1, 2) PTSS_TRI_CASE(1, 3)
+            PTSS_TRI_CASE(2, 0) PTSS_TRI_CASE(2, 1) PTSS_TRI_CASE(2, 3)
+            PTSS_TRI_CASE(3, 0) PTSS_TRI_CASE(3, 1) PTSS_TRI_CASE(3, 2)
+#undef PTSS_TRI_CASE
+            default: triangleForm<0, 0>(t, o3 + 3 * i, d3 + 3 * i, limit[i], primary != 0, out); break;
         }
     }
     return PTSS_HOST_OK;

@@ -56,6 +56,7 @@ def host_lib():
         L.ptss_tile_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.ptss_probe_math.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_size_t]
         L.ptss_probe_quantize.argtypes = [_f32p, C.POINTER(C.c_uint), C.c_size_t]
+        L.ptss_probe_triangle_forms.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_size_t, C.POINTER(C.c_int), _f32p, _f32p]
         L.ptss_probe_quant_table.argtypes = [_f32p]
         L.ptss_probe_rng_init.argtypes = [C.c_ulonglong, C.c_uint, _u32p]
         L.ptss_probe_rng_draw.argtypes = [_u32p, _u32p, _f32p, C.c_size_t]

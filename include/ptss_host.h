@@ -46,6 +46,11 @@ int ptss_probe_math(int op, const float* x, const float* y, float* out, size_t n
  * table form (csrc/ptquant.h): T[k] = smallest float whose sample is >= k (T[0] = -inf, T[256] = NaN). Returns PTSS_HOST_EINVAL if not monotone. */
 int ptss_probe_quantize(const float* x, unsigned int* out, size_t n);
 int ptss_probe_quant_table(float* out257);
+/* Triangle::intersectRay (Primitives.h:25-83) for n (triangle {v0, e1, e2}, origin, direction, running distance) tuples, in the
+ * general form and in the edge-class form the kernels pick for that triangle (csrc/pttri.h); primary != 0: with the
+ * camera-origin precomputes of bounce 0. cls[i] = the class; per form six floats: accepted (0/1), dist, b0, b1, b2, det. */
+int ptss_probe_triangle_forms(const float* tri9, const float* o3, const float* d3, const float* limit, int primary, size_t n, int* cls,
+                              float* general6, float* classed6);
 /* XORWOW state after curand_init(seed, subsequence, 0): out6 = v0..v4, d. */
 int ptss_probe_rng_init(unsigned long long seed, unsigned int subsequence, unsigned int* out6);
 /* n raw draws and the matching (0,1] floats from a state; state advanced in place. */

@@ -156,17 +156,20 @@ def test_lanes_with_callers_stream_and_buffers():
     r.close()
 
 
-def test_lanes_free_running_for_many_frames():
-    """Lanes are forked from the caller's stream only at a reset and may drift up to a frame apart: 600 ticks without a
-    synchronisation in between (and a camera move in the middle = a reset and a fork) must end on the one-lane image."""
+@pytest.mark.parametrize("S,ticks", [(1, 600), (5, 150)])
+def test_lanes_free_running_for_many_frames(S, ticks):
+    """Lanes are forked from the caller's stream only at a reset and may drift up to a frame apart: hundreds of ticks without a
+    synchronisation in between (and a camera move in the middle = a reset and a fork) must end on the one-lane image. With
+    S > 1 the pass's samples are added up by displayKernel on the CALLER's stream, behind the join, while the lanes are already
+    parking the next frame's: the sample words are double-buffered by frame parity (round 3; before, samples could be lost)."""
     scene = ptss.Scene("mixed")
     w, h, bounces = 640, 360, 8
     out = {}
     for lanes in (1, 2, 3):
-        r = ptss.Renderer(scene, w, h, max_iterations=bounces, sync_each_frame=False, frame_lanes=lanes, lanes_free_run=True)
+        r = ptss.Renderer(scene, w, h, max_iterations=bounces, sync_each_frame=False, frame_lanes=lanes, lanes_free_run=True, samples_per_pass=S)
         cam = ptss.default_camera()
-        for t in range(600):
-            if t == 250:
+        for t in range(ticks):
+            if t == ticks * 5 // 12:
                 cam.position.x = 0.125
                 r.set_camera(cam)
             r.generate_frame()

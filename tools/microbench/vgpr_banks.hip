@@ -85,6 +85,30 @@ __global__ __launch_bounds__(256, 7) void k(float* out, int iters) {
         ".if %2 == 22\n"  // 64-bit shift-add (address arithmetic of the ray planes)
         REP8("v_lshl_add_u64 v[40:41], v[32:33], 2, v[40:41]\n v_lshl_add_u64 v[44:45], v[32:33], 2, v[44:45]\n v_lshl_add_u64 v[48:49], v[32:33], 2, v[48:49]\n v_lshl_add_u64 v[52:53], v[32:33], 2, v[52:53]\n")
         ".endif\n"
+        ".if %2 == 23\n"  // 64-bit unsigned compare (the (distance, ~index) key of an order-free closest hit)
+        REP8("v_cmp_lt_u64_e64 s[22:23], v[32:33], v[34:35]\n v_cmp_lt_u64_e64 s[24:25], v[32:33], v[34:35]\n v_cmp_lt_u64_e64 s[22:23], v[32:33], v[34:35]\n v_cmp_lt_u64_e64 s[24:25], v[32:33], v[34:35]\n")
+        ".endif\n"
+        ".if %2 == 24\n"  // v_min3_f32
+        REP8("v_min3_f32 v40, v33, v34, v35\n v_min3_f32 v44, v33, v34, v35\n v_min3_f32 v48, v33, v34, v35\n v_min3_f32 v52, v33, v34, v35\n")
+        ".endif\n"
+        ".if %2 == 25\n"  // 32-bit unsigned compare VGPR, VGPR -> SGPR pair
+        REP8("v_cmp_lt_u32_e64 s[22:23], v33, v34\n v_cmp_lt_u32_e64 s[24:25], v33, v34\n v_cmp_lt_u32_e64 s[22:23], v33, v34\n v_cmp_lt_u32_e64 s[24:25], v33, v34\n")
+        ".endif\n"
+        ".if %2 == 26\n"  // v_cmp_class (one instruction for "positive normal/subnormal/zero/inf ...")
+        REP8("v_cmp_class_f32_e64 s[22:23], v33, v34\n v_cmp_class_f32_e64 s[24:25], v33, v34\n v_cmp_class_f32_e64 s[22:23], v33, v34\n v_cmp_class_f32_e64 s[24:25], v33, v34\n")
+        ".endif\n"
+        ".if %2 == 27\n"  // 32 scalar ALU instructions per trip (are they free beside the other waves' VALU? here: alone)
+        REP8("s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n")
+        ".endif\n"
+        ".if %2 == 28\n"  // 16 plain VALU + 16 SALU interleaved: does the scalar half hide?
+        REP8("v_mul_f32_e32 v40, v33, v34\n s_add_u32 s24, s24, 1\n v_mul_f32_e32 v44, v33, v34\n s_add_u32 s25, s25, 1\n")
+        ".endif\n"
+        ".if %2 == 29\n"  // 16 plain VALU + 16 taken scalar branches
+        REP8("v_mul_f32_e32 v40, v33, v34\n s_branch 2f\n s_nop 0\n 2:\n v_mul_f32_e32 v44, v33, v34\n s_branch 3f\n s_nop 0\n 3:\n")
+        ".endif\n"
+        ".if %2 == 30\n"  // v_max_f32 (clamp-style helpers)
+        REP8("v_max_f32_e32 v40, v33, v34\n v_max_f32_e32 v44, v33, v34\n v_max_f32_e32 v48, v33, v34\n v_max_f32_e32 v52, v33, v34\n")
+        ".endif\n"
         "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"
         "v_add_f32 %0, v40, v41\n v_add_f32 %0, %0, v44\n v_add_f32 %0, %0, v45\n v_add_f32 %0, %0, v48\n v_add_f32 %0, %0, v52\n"
         : "=v"(r)
@@ -138,6 +162,14 @@ int main() {
     run<20>("v_fma VOP3 (neg), three banks");
     run<21>("v_add3_u32 / v_lshl_add_u32");
     run<22>("v_lshl_add_u64");
+    run<23>("v_cmp_lt_u64 -> SGPR pair");
+    run<24>("v_min3_f32");
+    run<25>("v_cmp_lt_u32 v, v -> SGPR pair");
+    run<26>("v_cmp_class_f32 -> SGPR pair");
+    run<27>("32 x s_add_u32 (counted as 32 instructions)");
+    run<28>("16 x v_mul + 16 x s_add interleaved (per instruction of 32)");
+    run<29>("16 x v_mul + 16 taken s_branch (per instruction of 32; REP8 local labels)");
+    run<30>("v_max_f32");
     run<0>("v_fmac three banks (again)");
     return 0;
 }
