@@ -2,7 +2,8 @@
 
   libptss.so        hipcc --offload-arch=gfx950   csrc/*.hip        the product (kernels + C-ABI)
   libptss_host.so   g++                            host/*.cpp        host mirror (Scene, camera, TGA, probes)
-  ptss_main         hipcc (host only) + libptss    host/main.cpp     headless drop-in of the reference's main()
+  ptss_main         g++ (host only) + libptss      host/main.cpp     headless drop-in of the reference's main(); --gpus N: one
+                    + librccl                                       context per GPU, one ncclGather (host/MultiGpu.cpp)
 (The CPU oracle — test infrastructure — has its own recipe, oracle/build.py; nothing here refers to it.)
 
 Both sides of the parity contract are compiled with -ffp-contract=off and without fast-math
@@ -75,10 +76,10 @@ def build_device(force=False, defines=(), name="libptss.so"):
 def build_main(force=False):
     """ptss_main: the headless twin of the reference's executable (host C++ only; links the C-ABI + HIP runtime)."""
     out = os.path.join(LIBDIR, "ptss_main")
-    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "CudaTracer.cpp", "Scene.cpp", "HostOps.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "CudaTracer.cpp", "MultiGpu.cpp", "Scene.cpp", "HostOps.cpp")]
     if force or _newer(out, srcs + _headers() + [os.path.join(LIBDIR, "libptss.so")]):
         _run(["g++"] + CPU_FLAGS + ["-D__HIP_PLATFORM_AMD__", "-I", INC, "-I", CSRC, "-I", HOST, "-I", "/opt/rocm/include"] + srcs +
-             ["-L", LIBDIR, "-lptss", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+             ["-L", LIBDIR, "-lptss", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
               "-o", out])
     return out
 

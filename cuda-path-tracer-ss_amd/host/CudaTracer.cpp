@@ -13,6 +13,19 @@
 void generateFrame(uchar4* pixels, void* dataBlock, int ticks) {
     ProgramData* data = (ProgramData*)dataBlock;
     ptss_context* ctx = data->renderData.context;
+    data->lastTicks = ticks;
+    if (!data->shards.empty()) {   // several GPUs: every shard's generateFrame, side by side (MultiGpu.cpp)
+        generateFrameSharded(data, ticks);
+        if (data->resetTicksThisFrame) {
+            data->lastResetTick = ticks;
+            data->resetTicksThisFrame = false;
+        }
+        if (!data->quiet) {
+            std::cout << "Rays per pixel: " << ticks - data->lastResetTick << "  Time per pass: " << data->lastPassMs << "     \r";
+            std::cout.flush();
+        }
+        return;
+    }
 
     // the reference mutates ProgramData from Key(); push those fields down before the frame (:602-608, :620)
     if (data->resetTicksThisFrame) {
@@ -59,6 +72,8 @@ void Key(unsigned char key, int, int) {
 void saveScreenshot(char filename[160], int x, int y) {
     GPUAnimBitmap* bitmap = *(GPUAnimBitmap::get_bitmap_ptr());
     if (!bitmap || bitmap->width != x || bitmap->height != y) return;
-    const std::vector<uchar4> host = bitmap->read_pixels();
+    ProgramData* data = (ProgramData*)bitmap->dataBlock;
+    // several GPUs: the frame is on N devices — one RCCL gather of the accumulator tiles, un-tiled and scaled on the host
+    const std::vector<uchar4> host = data->shards.empty() ? bitmap->read_pixels() : displayFromAccumulator(data, gatherAccumulator(data), data->lastTicks);
     if (!writeTga(filename, reinterpret_cast<const ptss_uchar4*>(host.data()), x, y)) fprintf(stderr, "saveScreenshot: cannot write %s\n", filename);
 }

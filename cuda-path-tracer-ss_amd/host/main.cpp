@@ -3,8 +3,10 @@
 // device (one ptss_create instead of cudaMalloc x8 + cudaMemcpy x5 + curandSetupKernel), then
 // bitmap.anim_and_exit(generateFrame, NULL, Key). The reference ignores argv; this build accepts
 // optional overrides with the reference's values as defaults:
-//   ptss_main [--preset default] [--size 512x512] [--ticks 16] [--bounces 15] [--seed N]
+//   ptss_main [--preset default] [--size 512x512] [--ticks 16] [--bounces 15] [--seed N] [--samples-per-pass S]
 //             [--keys "wwd f"] [--out image.tga] [--quiet]
+//             [--gpus N]            the frame sharded by pixel tile over N GPUs of this node, one RCCL gather (MultiGpu.cpp)
+//             [--emulate-gpus N]    the same N shards on device 0, the gather as device copies (rehearsal on a one-GPU box)
 #include <stdlib.h>
 #include <string.h>
 
@@ -15,7 +17,8 @@
 
 int main(int argc, char* argv[]) {
     std::string preset = "default", out, keys;
-    int width = DIM, height = DIM, ticks = 16;
+    int width = DIM, height = DIM, ticks = 16, gpus = 0, samples = 1;
+    bool emulate = false;
     unsigned bounces = 15;
     unsigned long long seed = 0x5EED;
     bool quiet = false;
@@ -30,6 +33,9 @@ int main(int argc, char* argv[]) {
         else if (a == "--keys") keys = next();
         else if (a == "--out") out = next();
         else if (a == "--quiet") quiet = true;
+        else if (a == "--gpus") gpus = atoi(next());
+        else if (a == "--emulate-gpus") { gpus = atoi(next()); emulate = true; }
+        else if (a == "--samples-per-pass") samples = atoi(next());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
 
@@ -51,9 +57,15 @@ int main(int argc, char* argv[]) {
     cfg.height = height;
     cfg.maxIterations = bounces;
     cfg.seed = seed;
+    cfg.samplesPerPass = samples;
     const ptss_scene_desc desc = scene.desc(defaultColor);
     ptss_context* ctx = NULL;
-    PTSS_HANDLE(ptss_create(&desc, &cfg, &ctx));
+    if (gpus > 0) {   // one context, stream and display tile per GPU; RCCL communicator over them
+        createShards(data, desc, cfg, gpus, emulate);
+        ctx = data->renderData.context;
+    } else {
+        PTSS_HANDLE(ptss_create(&desc, &cfg, &ctx));
+    }
 
     // put values in a data block (:703-717)
     data->camera = Camera();
@@ -78,12 +90,14 @@ int main(int argc, char* argv[]) {
         name[sizeof(name) - 1] = 0;
         saveScreenshot(name, width, height);
     }
-    unsigned long long rays = 0;
-    PTSS_HANDLE(ptss_total_ray_bounces(ctx, &rays));
-    printf("%d ticks, %llu ray-bounces, last pass %.3f ms\n", ticks, rays, data->lastPassMs);
+    const unsigned long long rays = totalRayBounces(data);
+    printf("%d ticks, %llu ray-bounces, last pass %.3f ms", ticks, rays, data->lastPassMs);
+    if (gpus > 0) printf(", %d shard(s) on %s, gathered by %s", gpus, emulate ? "device 0" : "as many GPUs", emulate ? "device copies" : "ncclGather");
+    printf("\n");
 
     // free (:731-740)
-    PTSS_HANDLE(ptss_destroy(ctx));
+    if (gpus > 0) destroyShards(data);
+    else PTSS_HANDLE(ptss_destroy(ctx));
     bitmap.free_resources();
     delete data;
     return 0;

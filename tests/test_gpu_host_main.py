@@ -59,3 +59,29 @@ def test_main_default_arguments_are_the_reference_defaults(tmp_path):
     o = oracle.Oracle(ptss.Scene("default").desc, 512, 512, max_iterations=15)
     o.generate_frame()
     assert np.array_equal(rgb, o.pixels()[:, :3])
+
+
+def test_main_over_rccl_with_one_gpu_equals_the_single_gpu_path(tmp_path):
+    """ptss_main --gpus N (host/MultiGpu.cpp): one process, a context + stream per device, ncclCommInitAll, ONE ncclGather of the
+    accumulator tiles to device 0, un-tile + display scaling on the host. A one-GPU box can execute N = 1 — communicator,
+    gather, un-tile all run — and the screenshot must be the plain path's, byte for byte. (N > 1 on N devices: unexecuted.)"""
+    args = ["--preset", "mixed", "--size", "160x90", "--ticks", "5", "--bounces", "6"]
+    plain, out_plain = run_main(args, tmp_path)
+    rccl, out_rccl = run_main(args + ["--gpus", "1"], tmp_path)
+    assert np.array_equal(plain, rccl)
+    assert "1 shard(s) on as many GPUs, gathered by ncclGather" in out_rccl
+    assert out_plain.split(",")[1] == out_rccl.split(",")[1]      # the same ray-bounce total
+
+
+@pytest.mark.parametrize("shards,S", [(2, 1), (3, 1), (4, 2)])
+def test_main_sharded_on_one_gpu_reassembles_the_frame(tmp_path, shards, S):
+    """The same host path with N shards EMULATED on device 0 (--emulate-gpus: RCCL refuses two ranks on one device, so the
+    gather is done by device copies): N contexts on N streams, uneven shards (90 rows in bands of 8 over 3 or 4 shards), the
+    padded tiles, the un-tile and the display scaling. The frame equals the unsharded one (more than 128 rays stay alive
+    frame-wide at every bounce here, so the sharded loop guard never differs)."""
+    args = ["--preset", "mixed", "--size", "160x90", "--ticks", "4", "--bounces", "6", "--samples-per-pass", str(S)]
+    plain, out_plain = run_main(args, tmp_path)
+    sharded, out = run_main(args + ["--emulate-gpus", str(shards)], tmp_path)
+    assert np.array_equal(plain, sharded)
+    assert f"{shards} shard(s) on device 0, gathered by device copies" in out
+    assert out_plain.split(",")[1] == out.split(",")[1]
