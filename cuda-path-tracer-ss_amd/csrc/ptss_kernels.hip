@@ -320,6 +320,35 @@ __device__ __forceinline__ void triangleClassedAny(const float4* rows, vec3 o, v
         need &= ~hitMask;
     }
 }
+// ... and for the TWO segments of a surface point (pairAnyHit): the origin part once, a direction part per segment
+template <int kC1, int kC2>
+__device__ __forceinline__ void triangleClassedPair(const float4* rows, vec3 o, vec3 dA, float limitA, vec3 dB, float limitB, unsigned long long& needA,
+                                                    unsigned long long& needB, unsigned long long& blockedA, unsigned long long& blockedB) {
+    const vec3 e1 = xyz(loadRow16(rows + 1)), e2 = xyz(loadRow16(rows + 2));
+    const pttri::OriginPart p = pttri::originPart<kC1, kC2>(xyz(loadRow16(rows)), e1, e2, o);
+    if (needA != 0ull) {
+        const pttri::Head h = pttri::headFrom<kC1, kC2>(p, e1, e2, dA);
+        const unsigned long long pass = needA & maskOf(!(ptm::abs(h.det) <= 1e-7f)) & maskOf(!(h.dist <= 0.0f)) & maskOf(!(h.dist > limitA));
+        if (pass != 0ull) {
+            float b0, b1, b2;
+            pttri::weights<kC1, kC2>(h, dA, b0, b1, b2);
+            const unsigned long long hit = pass & maskOf(!(__builtin_fminf(__builtin_fminf(b0, b1), b2) < 0));
+            blockedA |= hit;
+            needA &= ~hit;
+        }
+    }
+    if (needB != 0ull) {
+        const pttri::Head h = pttri::headFrom<kC1, kC2>(p, e1, e2, dB);
+        const unsigned long long pass = needB & maskOf(!(ptm::abs(h.det) <= 1e-7f)) & maskOf(!(h.dist <= 0.0f)) & maskOf(!(h.dist > limitB));
+        if (pass != 0ull) {
+            float b0, b1, b2;
+            pttri::weights<kC1, kC2>(h, dB, b0, b1, b2);
+            const unsigned long long hit = pass & maskOf(!(__builtin_fminf(__builtin_fminf(b0, b1), b2) < 0));
+            blockedB |= hit;
+            needB &= ~hit;
+        }
+    }
+}
 // what the class bodies need of a query (pttri.h): a finite direction short enough to bound |det|, a finite origin
 __device__ __forceinline__ bool classedQueryOk(vec3 o, vec3 d) { return waveAll(dot(d, d) < 0x1p30f) && waveAll(dot(o, o) < 0x1p100f); }
 // ---- Primary (bounce 0) variants. Every eye ray starts at camera.position, so whatever the tests
@@ -1078,6 +1107,18 @@ __device__ __forceinline__ void pairAnyHit(const float4* sc, const SceneLayout& 
     unsigned long long needA = __ballot(liveA && !occA), needB = __ballot(liveB && !occB);
     unsigned long long blockedA = 0ull, blockedB = 0ull;
     const int triSteps = kSplit ? ((L.numTriangles + g - 1) >> shift) : L.numTriangles;
+    if constexpr (!kSplit) {   // every lane at the same triangle: one loop per edge class (grouped storage), origin part shared
+        if (L.triClassed && classedQueryOk(lo, wA) && waveAll(dot(wB, wB) < 0x1p30f)) {
+#define PTSS_PAIR_BODY(c1, c2, t)            \
+    if ((needA | needB) == 0ull) break;     \
+    triangleClassedPair<c1, c2>(sc + L.offTri + 3 * t, lo, wA, dA, wB, dB, needA, needB, blockedA, blockedB);
+            PTSS_FOR_TRIANGLES_BY_CLASS(L, PTSS_PAIR_BODY);
+#undef PTSS_PAIR_BODY
+            occA = occA || __builtin_amdgcn_inverse_ballot_w64(blockedA);
+            occB = occB || __builtin_amdgcn_inverse_ballot_w64(blockedB);
+            return;
+        }
+    }
     for (int k = 0; k < triSteps; ++k) {
         if ((needA | needB) == 0ull) break;
         const int idx = kSplit ? ((k << shift) + sub) : k;

@@ -83,24 +83,35 @@ struct Head {   // up to the distance test, Primitives.h:34-52
 };
 // kC1 / kC2: classes of e1 / e2. kPrimary: s, r and e2 . r come precomputed (every eye ray starts at the camera:
 // primaryPrepKernel evaluates them with the general form, so r's flagged components are exact zeros there as well).
-template <int kC1, int kC2, bool kPrimary>
-PTM_HD Head head(vec3 v0, vec3 e1, vec3 e2, vec3 ps, vec3 pr, float pe2r, vec3 o, vec3 d) {
+// the part that depends on the ray's ORIGIN only (two shadow segments leaving one surface point share it: pairAnyHit)
+struct OriginPart {
+    vec3 s, r;
+    float e2r;
+};
+template <int kC1, int kC2>
+PTM_HD OriginPart originPart(vec3 v0, vec3 e1, vec3 e2, vec3 o) {
+    OriginPart p;
+    p.s = o - v0;
+    p.r = crossEdge<kC1>(p.s, e1);
+    p.e2r = dotSkip<edgeZero(kC2, 0) || crossZero(kC1, 0), edgeZero(kC2, 1) || crossZero(kC1, 1), edgeZero(kC2, 2) || crossZero(kC1, 2)>(e2, p.r);
+    return p;
+}
+// ... and the part that depends on the direction, given the origin part
+template <int kC1, int kC2>
+PTM_HD Head headFrom(const OriginPart& p, vec3 e1, vec3 e2, vec3 d) {
     Head h;
     h.q = crossEdge<kC2>(d, e2);
     h.det = dotSkip<edgeZero(kC1, 0) || crossZero(kC2, 0), edgeZero(kC1, 1) || crossZero(kC2, 1), edgeZero(kC1, 2) || crossZero(kC2, 2)>(e1, h.q);
     h.inv = ptm::rcp_in_range(h.det);   // 1 / det, :44 — the caller has bounded |det| < 2^126 and discards results with |det| <= 1e-7
-    float e2r;
-    if constexpr (kPrimary) {
-        h.s = ps;
-        h.r = pr;
-        e2r = pe2r;
-    } else {
-        h.s = o - v0;
-        h.r = crossEdge<kC1>(h.s, e1);
-        e2r = dotSkip<edgeZero(kC2, 0) || crossZero(kC1, 0), edgeZero(kC2, 1) || crossZero(kC1, 1), edgeZero(kC2, 2) || crossZero(kC1, 2)>(e2, h.r);
-    }
-    h.dist = e2r * h.inv;
+    h.s = p.s;
+    h.r = p.r;
+    h.dist = p.e2r * h.inv;
     return h;
+}
+template <int kC1, int kC2, bool kPrimary>
+PTM_HD Head head(vec3 v0, vec3 e1, vec3 e2, vec3 ps, vec3 pr, float pe2r, vec3 o, vec3 d) {
+    if constexpr (kPrimary) return headFrom<kC1, kC2>(OriginPart{ps, pr, pe2r}, e1, e2, d);
+    else return headFrom<kC1, kC2>(originPart<kC1, kC2>(v0, e1, e2, o), e1, e2, d);
 }
 template <int kC1, int kC2>
 PTM_HD void weights(const Head& h, vec3 d, float& b0, float& b1, float& b2) {   // :55-64
