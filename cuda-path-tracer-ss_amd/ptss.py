@@ -65,9 +65,26 @@ def host_lib():
     return _host
 
 
+def _torch_first():
+    """PyTorch bundles its own HIP runtime and libptss.so links ROCm's; both may share a process, but torch's must initialise
+    first or a later torch.cuda call can fail with "No HIP GPUs are available" (INTEGRATION.md §5). If torch is already
+    imported, initialise it now — before libptss.so's runtime touches the device."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    try:
+        if torch.cuda.is_available() and not torch.cuda.is_initialized():
+            torch.cuda.init()
+    except Exception as e:  # pragma: no cover - depends on the box
+        raise PtssError("torch is imported but torch.cuda could not be initialised before libptss.so's HIP runtime "
+                        f"(INTEGRATION.md §5, two HIP runtimes in one process): {e}")
+
+
 def device_lib():
     """Loads libptss.so. Loading needs no GPU; ptss_create does."""
     global _dev
+    _torch_first()
     if _dev is None:
         if not os.path.exists(DEVICE_LIB):
             raise PtssError(f"{DEVICE_LIB} missing: the HIP extension was not built (no CPU fallback exists)")
