@@ -110,6 +110,7 @@ struct ptss_context {
     bool usePathTracer = true;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
+    bool oneLaunch = false, oneLaunchAlt = false;   // the frame is traced by ONE launch (frameKernel) with the current / the alternate scene image
     int gridCap = 0;             // workgroups per shard at most = 16 resident rounds of this scene's bounce kernel (0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
     unsigned frameIndex = 0;
@@ -446,12 +447,13 @@ void drainKernelEvents(ptss_context* c, bool wait) {
 // Frame lanes: did a lane give up waiting for a peer since the last check (FrameBuffers::guardTimeouts)? Called by the
 // entry points that have just synchronised; one 4-byte read-back, and only in contexts with more than one lane.
 int checkLaneTimeouts(ptss_context* c) {
-    if (c->lanes.size() < 2) return PTSS_OK;
+    if (c->lanes.size() < 2 && !c->oneLaunch && !c->oneLaunchAlt) return PTSS_OK;   // only kernels that wait for others can time out
     uint32_t v = 0;
     HIP_TRY(hipMemcpy(&v, c->dTotal + ptss::kMaxLanes + 8, sizeof(v), hipMemcpyDeviceToHost));
     if (v != c->timeoutsSeen) {
         c->timeoutsSeen = v;
-        return fail(PTSS_ETIMEOUT, "a frame lane gave up waiting for a peer lane: the frame's loop guard was decided without it");
+        return fail(PTSS_ETIMEOUT, "a bounded wait on the device expired (a frame lane for a peer lane, or a workgroup of the one-launch "
+                                   "frame kernel for its shard): the frame was not traced as specified");
     }
     return PTSS_OK;
 }
@@ -496,6 +498,7 @@ int ptss_default_config(ptss_render_config* cfg) {
     cfg->everySphereLoop = 0;
     cfg->frameLanes = 0;
     cfg->lanesFreeRun = 0;
+    cfg->oneLaunchFrames = 0;
     return PTSS_OK;
 }
 
@@ -702,6 +705,17 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
         const int perCU = ptss::bounceOccupancyBlocksPerCU(c->layout, c->sceneInLds, wantAccel);
         c->gridCap = prop.multiProcessorCount * (perCU > 0 ? perCU : 4) * 16 / ptss::kShards;
+        // One launch per frame (ptss_kernels.hip frameKernel): only when every workgroup of the frame's grid is resident at once —
+        // its workgroups wait for each other — i.e. bounce-0 tiles <= CUs x resident workgroups per CU of THAT kernel with this
+        // scene's LDS image. The occupancy API over-reports by one workgroup per CU for kernels of more than 96 SGPRs
+        // (MI355X_MICROARCH.md, "Residency and cooperative launch"): one is kept in reserve. One lane, scene staged in LDS.
+        auto qualifies = [&](const ptss::SceneLayout& lay, bool inLds) {
+            if (cfg->oneLaunchFrames <= 0 || numLanes != 1 || !inLds) return false;   // opt-in (include/ptss.h)
+            const int resident = ptss::frameOccupancyBlocksPerCU(lay, lay.sphereBounded != 0) - 1;
+            return resident >= 1 && c->lanes[0].maxBlocks <= prop.multiProcessorCount * resident;
+        };
+        c->oneLaunch = qualifies(c->layout, c->sceneInLds);
+        c->oneLaunchAlt = wantAccel && qualifies(c->layoutAlt, c->sceneInLdsAlt);
 #ifdef PTSS_TUNING_KNOBS   // measurement builds only (tools/build_variants.py "knobs"); the shipped library reads no environment
         if (const char* e = getenv("PTSS_SCENE_PATH")) {
             if (!strcmp(e, "scalar")) c->sceneInLds = c->sceneInLdsAlt = false;
@@ -774,6 +788,7 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             std::swap(c->dScene, c->dSceneAlt);
             std::swap(c->layout, c->layoutAlt);
             std::swap(c->sceneInLds, c->sceneInLdsAlt);
+            std::swap(c->oneLaunch, c->oneLaunchAlt);
             c->accelActive = want;
             c->cameraDirty = true;
         }
@@ -846,6 +861,30 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
     if (c->cfg.timeKernels) drainKernelEvents(c, false);
     // the shorter sphere candidate test: bounded geometry AND a camera within the same range (ray origins are the camera or points on primitives)
     const bool bounded = c->layout.sphereBounded != 0 && cameraInRange(c->camera);
+    // The frame kernel's bounded form of the sphere test needs what the bounce kernels' needs (above); its grid is the frame's tiles.
+    if (c->oneLaunch && K == 1) {   // every bounce in ONE launch (frameKernel): :622-633 without leaving the device
+        Lane& ln = c->lanes[0];
+        EventPair ev{nullptr, nullptr};
+        if (c->cfg.timeKernels) {
+            if (c->evFree.empty()) {
+                if (c->evBusy.size() >= 4096) drainKernelEvents(c, true);
+                if (c->evFree.empty()) {
+                    HIP_TRY(hipEventCreate(&ev.a));
+                    HIP_TRY(hipEventCreate(&ev.b));
+                }
+            }
+            if (!ev.a) {
+                ev = c->evFree.back();
+                c->evFree.pop_back();
+            }
+            HIP_TRY(hipEventRecord(ev.a, st));
+        }
+        HIP_TRY(ptss::launchFrame(st, fbs[0], c->dScene, c->layout, numIterations, bounded, ln.maxBlocks, c->tile, eye));
+        if (c->cfg.timeKernels) {
+            HIP_TRY(hipEventRecord(ev.b, st));
+            c->evBusy.push_back(ev);
+        }
+    } else
     for (int i = 0; i < numIterations; ++i) {  // :622-633, guard evaluated on the device
         for (int k = 0; k < K; ++k) {
             Lane& ln = c->lanes[(size_t)k];
@@ -1127,6 +1166,12 @@ int ptss_guard_timeouts(ptss_context* c, unsigned int* out) {
     uint32_t v = 0;
     HIP_TRY(hipMemcpy(&v, c->dTotal + ptss::kMaxLanes + 8, sizeof(v), hipMemcpyDeviceToHost));
     *out = v;
+    return PTSS_OK;
+}
+
+int ptss_one_launch_frames(const ptss_context* c, int* out) {
+    if (!c || !out) return fail(PTSS_EINVAL, "null argument");
+    *out = (c->oneLaunch && c->lanes.size() == 1) ? 1 : 0;
     return PTSS_OK;
 }
 

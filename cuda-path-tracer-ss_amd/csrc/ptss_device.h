@@ -205,6 +205,9 @@ hipError_t launchPrimaryPrep(hipStream_t st, float4* sceneBlob, const SceneLayou
 hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int bounce,
                         bool isLast, bool sceneInLds, bool bounded, int gridBlocks, TileMap tile, EyeParams eye);
 size_t bounceLdsBytes(const SceneLayout& layout, bool sceneInLds);
+hipError_t launchFrame(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int numBounces, bool bounded, int gridBlocks,
+                       TileMap tile, EyeParams eye);   // every bounce of a frame in ONE launch (frameKernel): the whole grid must be resident
+int frameOccupancyBlocksPerCU(const SceneLayout& layout, bool bounded);
 struct FlushTargets {  // flushKernel re-derives the guard of every bounce: target[p][b] = peer p's done total after ITS bounce b of this frame
     uint32_t target[kMaxLanes - 1][kMaxBounces + 1];
 };

@@ -89,57 +89,71 @@ __device__ __forceinline__ uint32_t slotWord(uint32_t slot) {  // word offset of
 
 // One word of a block: scalar base + (32-bit lane byte offset, zero-extended) + compile-time plane offset — the form
 // global_load/store take as `saddr + voffset + imm` (no 64-bit vector address pair per group of planes).
+// kCoherent (the one-launch-per-frame kernel, frameKernel): the word was written, or will be read, by ANOTHER workgroup of the
+// same launch — relaxed agent-scope accesses (global_load / global_store ... sc1: past the CU's L1, written through), the
+// payload half of the sc1 hand-off of MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility".
+template <bool kCoherent = false>
 __device__ __forceinline__ float ldPlane(const float* __restrict__ block, uint32_t laneBytes, int plane) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(block) + (size_t)laneBytes + (size_t)plane * (kBlock * sizeof(float)));
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(block) + (size_t)laneBytes + (size_t)plane * (kBlock * sizeof(float)));
+    if constexpr (kCoherent) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
 }
+template <bool kCoherent = false>
 __device__ __forceinline__ void stPlane(float* __restrict__ region, uint32_t wordBytes, int plane, float v) {
-    *reinterpret_cast<float*>(reinterpret_cast<char*>(region) + (size_t)wordBytes + (size_t)plane * (kBlock * sizeof(float))) = v;
+    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(region) + (size_t)wordBytes + (size_t)plane * (kBlock * sizeof(float)));
+    if constexpr (kCoherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // A tile fetches a ray's planes in the order it needs them, so that no plane occupies registers before
 // its consumer runs: origin + direction for the closest-hit loops, the XORWOW state for the light samples, radiance /
 // throughput / pixel for the update at the end. `block` = the tile's block (wave-uniform), w = the ray's lane in it.
+template <bool kCoherent = false>
 __device__ __forceinline__ void loadRayGeometry(const float* __restrict__ block, uint32_t w, RayRegs& r) {
     const uint32_t b = w * 4u;
-    r.o = vec3{ldPlane(block, b, kOx), ldPlane(block, b, kOy), ldPlane(block, b, kOz)};
-    r.d = vec3{ldPlane(block, b, kDx), ldPlane(block, b, kDy), ldPlane(block, b, kDz)};
+    r.o = vec3{ldPlane<kCoherent>(block, b, kOx), ldPlane<kCoherent>(block, b, kOy), ldPlane<kCoherent>(block, b, kOz)};
+    r.d = vec3{ldPlane<kCoherent>(block, b, kDx), ldPlane<kCoherent>(block, b, kDy), ldPlane<kCoherent>(block, b, kDz)};
     r.active = true;
 }
+template <bool kCoherent = false>
 __device__ __forceinline__ void loadRayRng(const float* __restrict__ block, uint32_t w, RayRegs& r) {
     const uint32_t b = w * 4u;
-    r.rng.v[0] = asU(ldPlane(block, b, kR0));
-    r.rng.v[1] = asU(ldPlane(block, b, kR1));
-    r.rng.v[2] = asU(ldPlane(block, b, kR2));
-    r.rng.v[3] = asU(ldPlane(block, b, kR3));
-    r.rng.v[4] = asU(ldPlane(block, b, kR4));
-    r.rng.d = asU(ldPlane(block, b, kRd));
+    r.rng.v[0] = asU(ldPlane<kCoherent>(block, b, kR0));
+    r.rng.v[1] = asU(ldPlane<kCoherent>(block, b, kR1));
+    r.rng.v[2] = asU(ldPlane<kCoherent>(block, b, kR2));
+    r.rng.v[3] = asU(ldPlane<kCoherent>(block, b, kR3));
+    r.rng.v[4] = asU(ldPlane<kCoherent>(block, b, kR4));
+    r.rng.d = asU(ldPlane<kCoherent>(block, b, kRd));
 }
+template <bool kCoherent = false>
 __device__ __forceinline__ void loadRayRadiance(const float* __restrict__ block, uint32_t w, RayRegs& r) {
     const uint32_t b = w * 4u;
-    r.L0 = vec3{ldPlane(block, b, kL0x), ldPlane(block, b, kL0y), ldPlane(block, b, kL0z)};
-    r.T = vec3{ldPlane(block, b, kTx), ldPlane(block, b, kTy), ldPlane(block, b, kTz)};
-    r.pix = asU(ldPlane(block, b, kPix));
+    r.L0 = vec3{ldPlane<kCoherent>(block, b, kL0x), ldPlane<kCoherent>(block, b, kL0y), ldPlane<kCoherent>(block, b, kL0z)};
+    r.T = vec3{ldPlane<kCoherent>(block, b, kTx), ldPlane<kCoherent>(block, b, kTy), ldPlane<kCoherent>(block, b, kTz)};
+    r.pix = asU(ldPlane<kCoherent>(block, b, kPix));
 }
+template <bool kCoherent = false>
 __device__ __forceinline__ void loadRay(const float* __restrict__ block, uint32_t w, RayRegs& r) {
-    loadRayGeometry(block, w, r);
-    loadRayRng(block, w, r);
-    loadRayRadiance(block, w, r);
+    loadRayGeometry<kCoherent>(block, w, r);
+    loadRayRng<kCoherent>(block, w, r);
+    loadRayRadiance<kCoherent>(block, w, r);
 }
 
 // the ray goes to region slot `slot` (its word in plane 0 of its block: slotWord)
+template <bool kCoherent = false>
 __device__ __forceinline__ void storeRay(float* __restrict__ region, uint32_t slot, const RayRegs& r) {
     const uint32_t b = slotWord(slot) * 4u;   // < 2^32: ptss_create bounds a region's bytes
-    stPlane(region, b, kOx, r.o.x);   stPlane(region, b, kOy, r.o.y);   stPlane(region, b, kOz, r.o.z);
-    stPlane(region, b, kDx, r.d.x);   stPlane(region, b, kDy, r.d.y);   stPlane(region, b, kDz, r.d.z);
-    stPlane(region, b, kL0x, r.L0.x); stPlane(region, b, kL0y, r.L0.y); stPlane(region, b, kL0z, r.L0.z);
-    stPlane(region, b, kTx, r.T.x);   stPlane(region, b, kTy, r.T.y);   stPlane(region, b, kTz, r.T.z);
-    stPlane(region, b, kPix, asF(r.pix));
-    stPlane(region, b, kR0, asF(r.rng.v[0]));
-    stPlane(region, b, kR1, asF(r.rng.v[1]));
-    stPlane(region, b, kR2, asF(r.rng.v[2]));
-    stPlane(region, b, kR3, asF(r.rng.v[3]));
-    stPlane(region, b, kR4, asF(r.rng.v[4]));
-    stPlane(region, b, kRd, asF(r.rng.d));
+    stPlane<kCoherent>(region, b, kOx, r.o.x);   stPlane<kCoherent>(region, b, kOy, r.o.y);   stPlane<kCoherent>(region, b, kOz, r.o.z);
+    stPlane<kCoherent>(region, b, kDx, r.d.x);   stPlane<kCoherent>(region, b, kDy, r.d.y);   stPlane<kCoherent>(region, b, kDz, r.d.z);
+    stPlane<kCoherent>(region, b, kL0x, r.L0.x); stPlane<kCoherent>(region, b, kL0y, r.L0.y); stPlane<kCoherent>(region, b, kL0z, r.L0.z);
+    stPlane<kCoherent>(region, b, kTx, r.T.x);   stPlane<kCoherent>(region, b, kTy, r.T.y);   stPlane<kCoherent>(region, b, kTz, r.T.z);
+    stPlane<kCoherent>(region, b, kPix, asF(r.pix));
+    stPlane<kCoherent>(region, b, kR0, asF(r.rng.v[0]));
+    stPlane<kCoherent>(region, b, kR1, asF(r.rng.v[1]));
+    stPlane<kCoherent>(region, b, kR2, asF(r.rng.v[2]));
+    stPlane<kCoherent>(region, b, kR3, asF(r.rng.v[3]));
+    stPlane<kCoherent>(region, b, kR4, asF(r.rng.v[4]));
+    stPlane<kCoherent>(region, b, kRd, asF(r.rng.d));
 }
 
 // ---- Sphere::intersectRay, Primitives.h:107-175. sp = {centre, radius^2}. ---------------------
@@ -1552,53 +1566,37 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
 // eye ray in registers (no ray pool read) and intersects with the camera-origin precomputes.
 // kAccel: the scene image carries the chunked sphere structure (SceneLayout::accelSpheres) — its own instantiations, so
 // that scenes without it run exactly the code they ran before.
-template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairsWanted>
-__device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
-                                           const TileMap& tile, const EyeParams& eye) {
-    extern __shared__ float4 lds[];
-    constexpr bool kPairs = kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
-    const uint32_t shard = blockIdx.x % kShards;
-    const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
-    if constexpr (kFirst) {
-        if (fb.frameRays <= fb.minLive) return;  // loop guard, CudaTracer.cu:622: the frame starts with <= 128 rays
-    } else {
-        if (n == 0) return;  // nothing of this shard reached this bounce (whatever the guard says)
-        if (n <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
-            uint32_t own = 0;   // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
-            for (int s = 0; s < kShards; ++s) own += fb.counts[countIndex(bounce, s)];
-            if (own <= fb.minLive && frameLiveCount(fb, bounce, own, fb.peerTarget) <= fb.minLive) return;
-        }
-    }
+// What one workgroup needs to trace one tile (bounceTile): the staged scene, this bounce's input and output regions of its
+// shard, the wave's LDS queue. Built by bounceBody (one launch per bounce) and by frameKernel (one launch per frame).
+struct TileEnv {
+    const float4* sc;          // the scene image as the tile reads it (LDS or global)
+    const float4* sceneBlob;   // ... in global memory (the many-sphere image's cold integer tables)
+    const float* quantT;
+    const float* in;           // this shard's region of the input pool
+    float* out;                // ... of the output pool
+    float* wq;                 // this wave's LDS queue
+    uint32_t* wqOwner;
+    unsigned char* wqAnswer;
+    uint32_t shard, lane, n;   // n: rays of this shard entering the bounce
+    int numLights, bounce;
+};
 
-    const uint32_t lane = __lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
-    float4* work = lds + (kSceneInLds ? L.ldsVec4 : 0);
-    float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
-    uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
-    unsigned char* wqAnswer = reinterpret_cast<unsigned char*>(wqOwner + kQueueCap);  // [kNeeLights][64], 0 / 1
-
-    const float4* sc;
-    if constexpr (kSceneInLds) {
-        for (int k = threadIdx.x; k < L.ldsVec4; k += kBlock) lds[k] = sceneBlob[k];
-        __syncthreads();
-        sc = lds;
-    } else {
-        sc = sceneBlob;
-    }
-    const float* quantT = reinterpret_cast<const float*>(sc + L.offQuant);
-
-    const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
-    const float* __restrict__ in = fb.pool[bounce & 1] + shard * regionWords;  // this shard's region
-    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * regionWords;
-    const int numLights = L.numPointLights + L.numAreaLights;
-
-    // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
-    // bounce 0 walks the FRAME's tiles (S sample planes of fb.plane pixels; tile t belongs to shard t % kShards),
-    // every later bounce walks the shard's compacted region
-    // (with frame lanes: round R of the frame belongs to lane R % laneCount, whose round R / laneCount it is)
-    const uint32_t roundsOfShard = (fb.firstTiles + kShards - 1 - shard) / kShards;
-    const uint32_t span = kFirst ? ((roundsOfShard + fb.laneCount - 1 - fb.laneIndex) / fb.laneCount) * kBlock : n;
-    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock) {
+// One tile = kBlock rays of bounce env.bounce, starting at slot / frame-tile offset `base` of the shard. kCoherentIo: the ray
+// pools are read and written past the L1 (ldPlane<true>): other workgroups of the SAME launch produced / will consume them.
+template <bool kLast, bool kFirst, bool kAccel, bool kBounded, bool kPairs, bool kCoherentIo>
+__device__ __forceinline__ void bounceTile(const FrameBuffers& fb, const SceneLayout& L, const TileMap& tile, const EyeParams& eye, const TileEnv& env,
+                                           uint32_t base) {
+    const float4* sc = env.sc;
+    const float4* sceneBlob = env.sceneBlob;
+    const float* quantT = env.quantT;
+    const float* __restrict__ in = env.in;
+    float* __restrict__ out = env.out;
+    float* wq = env.wq;
+    uint32_t* wqOwner = env.wqOwner;
+    unsigned char* wqAnswer = env.wqAnswer;
+    const uint32_t shard = env.shard, lane = env.lane, n = env.n;
+    const int numLights = env.numLights, bounce = env.bounce;
+    {
         const uint32_t i = base + threadIdx.x;
         uint32_t firstPixel = 0, firstLane = 0;
         bool valid = i < n;
@@ -1634,7 +1632,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
         } else {
             // a ray's planes are fetched where the tile first needs them (origin/direction here, the RNG state before the light
             // samples, radiance/throughput/pixel before the update): 13 fewer live registers across the closest-hit loops
-            if (valid) loadRayGeometry(tileBlock(in, base), threadIdx.x, ray);
+            if (valid) loadRayGeometry<kCoherentIo>(tileBlock(in, base), threadIdx.x, ray);
         }
 #if PTSS_ABLATE & 2
         Hit h;
@@ -1645,7 +1643,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
 #endif
         const bool hit = valid && h.kind != 0;
         if constexpr (!kFirst) {
-            if (valid) loadRayRng(tileBlock(in, base), threadIdx.x, ray);
+            if (valid) loadRayRng<kCoherentIo>(tileBlock(in, base), threadIdx.x, ray);
         }
         vec3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
         float cosI = 0;
@@ -1844,7 +1842,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
         // ---- 3. scatter + radiance update (pathTraceKernel :172-198) -------------------------------
         bool alive = false;
         if constexpr (!kFirst) {
-            if (valid) loadRayRadiance(tileBlock(in, base), threadIdx.x, ray);
+            if (valid) loadRayRadiance<kCoherentIo>(tileBlock(in, base), threadIdx.x, ray);
         }
         if (valid) {
             if (hit) {
@@ -1883,13 +1881,65 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                 slot = base0;  // consumed after the finish work below
                 if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
                 slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
-                if (alive) storeRay(out, slot, ray);
+                if (alive) storeRay<kCoherentIo>(out, slot, ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
                 finishPath(fb, ray, quantT);
             }
         } else {
             if (valid && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
         }
+    }
+}
+
+template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairsWanted>
+__device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
+                                           const TileMap& tile, const EyeParams& eye) {
+    extern __shared__ float4 lds[];
+    constexpr bool kPairs = kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
+    const uint32_t shard = blockIdx.x % kShards;
+    const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
+    if constexpr (kFirst) {
+        if (fb.frameRays <= fb.minLive) return;  // loop guard, CudaTracer.cu:622: the frame starts with <= 128 rays
+    } else {
+        if (n == 0) return;  // nothing of this shard reached this bounce (whatever the guard says)
+        if (n <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
+            uint32_t own = 0;   // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
+            for (int s = 0; s < kShards; ++s) own += fb.counts[countIndex(bounce, s)];
+            if (own <= fb.minLive && frameLiveCount(fb, bounce, own, fb.peerTarget) <= fb.minLive) return;
+        }
+    }
+
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    float4* work = lds + (kSceneInLds ? L.ldsVec4 : 0);
+    float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;  // this wave's queue
+    uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
+    unsigned char* wqAnswer = reinterpret_cast<unsigned char*>(wqOwner + kQueueCap);  // [kNeeLights][64], 0 / 1
+
+    const float4* sc;
+    if constexpr (kSceneInLds) {
+        for (int k = threadIdx.x; k < L.ldsVec4; k += kBlock) lds[k] = sceneBlob[k];
+        __syncthreads();
+        sc = lds;
+    } else {
+        sc = sceneBlob;
+    }
+    const float* quantT = reinterpret_cast<const float*>(sc + L.offQuant);
+
+    const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
+    const float* __restrict__ in = fb.pool[bounce & 1] + shard * regionWords;  // this shard's region
+    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * regionWords;
+    const int numLights = L.numPointLights + L.numAreaLights;
+    const TileEnv env{sc, sceneBlob, quantT, in, out, wq, wqOwner, wqAnswer, shard, lane, n, numLights, bounce};
+
+    // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
+    // bounce 0 walks the FRAME's tiles (S sample planes of fb.plane pixels; tile t belongs to shard t % kShards),
+    // every later bounce walks the shard's compacted region
+    // (with frame lanes: round R of the frame belongs to lane R % laneCount, whose round R / laneCount it is)
+    const uint32_t roundsOfShard = (fb.firstTiles + kShards - 1 - shard) / kShards;
+    const uint32_t span = kFirst ? ((roundsOfShard + fb.laneCount - 1 - fb.laneIndex) / fb.laneCount) * kBlock : n;
+    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock) {
+        bounceTile<kLast, kFirst, kAccel, kBounded, kPairs, false>(fb, L, tile, eye, env, base);
     }
 }
 
@@ -1905,6 +1955,141 @@ __global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST 
         __syncthreads();
         if (threadIdx.x == 0)
             __hip_atomic_fetch_add(fb.myDone + countIndex(bounce, (int)(blockIdx.x % kShards)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- ONE LAUNCH PER FRAME (frames whose bounce-0 tiles are all resident at once: up to ~3 * 2^17 rays per pass) -------------
+// A pass of a small frame is up to 16 launches that are each at most one resident round wide: such a launch costs what ONE
+// tile costs from end to end (~15 us at 512 x 512: scene staging, ray fetch, ~3,300 dependent instructions, the counter
+// round trip) whatever the machine could do meanwhile. Here workgroup w = (shard s = w % kShards, tile j =
+// w / kShards) stays: it stages the scene once, traces bounce-0 tile j of its shard, and then, bounce after bounce, tile j of
+// the shard's compacted region for as long as that tile exists (a region never grows, so a workgroup that finds its tile
+// beyond the count is done for good).
+// Hand-off between the bounces of ONE shard (the only dependency: survivors are compacted per shard): every workgroup that
+// traced a tile of bounce b adds 1 to done[b][s] — word kDoneWord of the (b, s) counter line — after its waves have drained
+// their stores (s_waitcnt vmcnt(0), workgroup barrier); a workgroup goes on to bounce b + 1 when done[b][s] has reached the
+// tiles the shard had at bounce b (it knows: ceil(n_s(b) / 256)), and then reads n_s(b + 1), raised by returning atomics
+// before those arrivals. The rays themselves cross between workgroups through sc1 accesses (ldPlane<true> / stPlane<true>):
+// written through, read past the L1 — MI355X_MICROARCH.md's hand-off "one lane of each storing workgroup signals by an
+// agent-scope atomic add, the consumer polls that counter with sc1 loads, payload stored and loaded sc1" (no L2 write-back,
+// no L1 invalidate per bounce). The loop guard `numRays > 128` (CudaTracer.cu:622) is a whole-frame count: a workgroup whose
+// shard still holds more than 128 rays knows the frame does; otherwise lanes 0..15 of its first wave each follow one shard's
+// chain of done counters up to this bounce (a few loads, progress kept in registers) and add the shards' counts up.
+// Deadlock freedom: the host launches this kernel only when the whole grid is resident at once (ptss_api.hip), so every
+// workgroup a waiter depends on is running or has finished; every wait is bounded all the same (peerWaitExpired) and a
+// workgroup whose wait expires leaves — the host then reports PTSS_ETIMEOUT.
+constexpr int kDoneWord = 1;
+
+__device__ __forceinline__ bool waitForCount(const uint32_t* word, uint32_t target) {   // bounded; true = reached
+    unsigned long long since = 0ull;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (peerWaitExpired(since)) return false;
+    }
+    return true;
+}
+
+template <bool kAccel, bool kBounded, bool kPairsWanted>
+__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES)) void frameKernel(
+    FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int numBounces, TileMap tile, EyeParams eye) {
+    extern __shared__ float4 lds[];
+    constexpr bool kPairs = kPairsWanted && !kAccel;
+    if (fb.frameRays <= fb.minLive) return;   // loop guard at bounce 0: the frame starts with <= 128 rays
+    const uint32_t shard = blockIdx.x % kShards, myTile = blockIdx.x / kShards;
+    const uint32_t rounds = (fb.firstTiles + kShards - 1 - shard) / kShards;   // bounce-0 tiles of this shard
+    if (myTile >= rounds) return;
+
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    float4* work = lds + L.ldsVec4;
+    uint32_t* bcast = reinterpret_cast<uint32_t*>(work);   // [0] rays of this shard entering the next bounce (~0u: give up), [1] the frame's
+    float* wq = reinterpret_cast<float*>(work + kBlockScratchVec4) + wave * kWaveLdsWords;
+    uint32_t* wqOwner = reinterpret_cast<uint32_t*>(wq + 7 * kQueueCap);
+    unsigned char* wqAnswer = reinterpret_cast<unsigned char*>(wqOwner + kQueueCap);
+    for (int k = threadIdx.x; k < L.ldsVec4; k += kBlock) lds[k] = sceneBlob[k];   // the scene, once per frame
+    __syncthreads();
+    const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
+    TileEnv env{lds, sceneBlob, reinterpret_cast<const float*>(lds + L.offQuant), nullptr, nullptr, wq, wqOwner, wqAnswer, shard, lane, 0u,
+                L.numPointLights + L.numAreaLights, 0};
+    uint32_t tilesNow = rounds, raysNow = 0;
+    // the guard's view of the other shards (lanes 0..15 of wave 0, one shard each): the next bounce to verify, -1 = that shard is empty
+    int verified = 0;
+    for (int b = 0; b < numBounces; ++b) {
+        const bool last = b == numBounces - 1;
+        env.bounce = b;
+        env.n = raysNow;
+        env.in = fb.pool[b & 1] + shard * regionWords;
+        env.out = fb.pool[(b + 1) & 1] + shard * regionWords;
+        const uint32_t base = myTile * kBlock;
+        if (b == 0) {
+            if (last) bounceTile<true, true, kAccel, kBounded, kPairs, true>(fb, L, tile, eye, env, base);
+            else bounceTile<false, true, kAccel, kBounded, kPairs, true>(fb, L, tile, eye, env, base);
+        } else if (last) {
+            bounceTile<true, false, kAccel, kBounded, kPairs, true>(fb, L, tile, eye, env, base);
+        } else {
+            bounceTile<false, false, kAccel, kBounded, kPairs, true>(fb, L, tile, eye, env, base);
+        }
+        if (last) break;
+        // publish this tile (its survivors are in the output region, the shard's next count was raised by returning atomics) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(fb.counts + countIndex(b, (int)shard) + kDoneWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and wait for the shard's other tiles of this bounce; n_s(b + 1) is final once those arrivals are complete
+            const uint32_t* done = fb.counts + countIndex(b, (int)shard) + kDoneWord;
+            uint32_t next = ~0u;
+            unsigned long long since = 0ull;
+            for (;;) {
+                if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tilesNow) {
+                    next = __hip_atomic_load(fb.counts + countIndex(b + 1, (int)shard), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (peerWaitExpired(since)) {
+                    atomicAdd(fb.guardTimeouts, 1u);
+                    break;
+                }
+            }
+            bcast[0] = next;
+        }
+        __syncthreads();
+        const uint32_t next = bcast[0];
+        if (next == ~0u) return;
+        if (myTile * kBlock >= next) return;   // no tile of bounce b + 1 for this workgroup, nor of any later bounce
+        if (next <= fb.minLive) {   // the loop guard is the FRAME's count: ask the other shards (wave 0, one lane per shard)
+            if (wave == 0) {
+                uint32_t theirs = 0;
+                bool ok = true;
+                if (lane < kShards) {
+                    const int s = (int)lane;
+                    while (verified >= 0 && verified <= b) {   // every bounce up to b of shard s must have ended before its count of b + 1 is final
+                        const uint32_t tiles = verified == 0 ? (fb.firstTiles + kShards - 1 - (uint32_t)s) / kShards
+                                                             : (__hip_atomic_load(fb.counts + countIndex(verified, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + kBlock - 1) / kBlock;
+                        if (tiles == 0) {
+                            verified = -1;   // nothing of shard s reached this bounce: nothing ever will
+                        } else if (waitForCount(fb.counts + countIndex(verified, s) + kDoneWord, tiles)) {
+                            ++verified;
+                        } else {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (verified > b) theirs = __hip_atomic_load(fb.counts + countIndex(b + 1, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t total = theirs;
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) total += (uint32_t)__shfl_xor((int)total, off);
+                const bool allOk = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                if (lane == 0) {
+                    if (!allOk) atomicAdd(fb.guardTimeouts, 1u);
+                    bcast[1] = allOk ? total : 0u;   // a wait that expired: leave (as if the guard had stopped the frame)
+                }
+            }
+            __syncthreads();
+            if (bcast[1] <= fb.minLive) return;
+        }
+        tilesNow = (next + kBlock - 1) / kBlock;
+        raysNow = next;
     }
 }
 
@@ -1995,6 +2180,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
         const int b = k / kShards, s = k % kShards;
         fb.lastCounts[countIndex(b, s)] = (b <= numBounces) ? fb.counts[countIndex(b, s)] : 0u;
         fb.countsNext[countIndex(b, s)] = (b == 0) ? fb.shardCount0[s] : 0u;
+        fb.countsNext[countIndex(b, s) + kDoneWord] = 0u;   // frameKernel's finished-tiles counter of that line
     }
     // This lane has finished the frame: every read of a peer's counters (thread 0, above) has returned by now, and what this
     // kernel wrote — finishPath's accumulator / pixel / float-sum / RNG words of the leftover rays, lastCounts, countsNext, the
@@ -2086,6 +2272,32 @@ hipError_t launchBounce(hipStream_t st, const FrameBuffers& fb, const float4* sc
     if (isFirst) { if (isLast) PTSS_GO(true, false, true); else PTSS_GO(false, false, true); }
     if (isLast) PTSS_GO(true, false, false); else PTSS_GO(false, false, false);
 #undef PTSS_GO
+}
+
+template <bool kAccel, bool kBounded, bool kPairs>
+static hipError_t launchFrameT(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, const SceneLayout& layout, int numBounces, int gridBlocks,
+                               const TileMap& tile, const EyeParams& eye) {
+    hipLaunchKernelGGL((frameKernel<kAccel, kBounded, kPairs>), dim3(gridBlocks), dim3(kBlock), bounceLdsBytes(layout, true), st, fb, sceneBlob, layout,
+                       numBounces, tile, eye);
+    return hipGetLastError();
+}
+hipError_t launchFrame(hipStream_t st, const FrameBuffers& fb, const float4* sceneBlob, SceneLayout layout, int numBounces, bool bounded, int gridBlocks,
+                       TileMap tile, EyeParams eye) {
+    if (layout.accelSpheres) return launchFrameT<true, false, false>(st, fb, sceneBlob, layout, numBounces, gridBlocks, tile, eye);
+    if (bounded && layout.neePairs) return launchFrameT<false, true, true>(st, fb, sceneBlob, layout, numBounces, gridBlocks, tile, eye);
+    if (bounded) return launchFrameT<false, true, false>(st, fb, sceneBlob, layout, numBounces, gridBlocks, tile, eye);
+    return launchFrameT<false, false, false>(st, fb, sceneBlob, layout, numBounces, gridBlocks, tile, eye);
+}
+// resident workgroups per CU of the frame kernel `layout` would run (the API's answer; the caller keeps one in reserve)
+int frameOccupancyBlocksPerCU(const SceneLayout& layout, bool bounded) {
+    const size_t lds = bounceLdsBytes(layout, true);
+    int a = 0;
+    hipError_t e;
+    if (layout.accelSpheres) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, frameKernel<true, false, false>, kBlock, lds);
+    else if (bounded && layout.neePairs) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, frameKernel<false, true, true>, kBlock, lds);
+    else if (bounded) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, frameKernel<false, true, false>, kBlock, lds);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, frameKernel<false, false, false>, kBlock, lds);
+    return e == hipSuccess ? a : 0;
 }
 
 hipError_t launchFlush(hipStream_t st, const FrameBuffers& fb, int numBounces, const FlushTargets& targets) {

@@ -33,7 +33,7 @@ class RenderConfig(C.Structure):
                 ("device", C.c_int), ("tileRank", C.c_int), ("tileWorld", C.c_int), ("bandRows", C.c_int),
                 ("syncEachFrame", C.c_int), ("floatAccumulator", C.c_int), ("timeKernels", C.c_int),
                 ("samplesPerPass", C.c_int), ("everySphereLoop", C.c_int), ("frameLanes", C.c_int),
-                ("lanesFreeRun", C.c_int)]
+                ("lanesFreeRun", C.c_int), ("oneLaunchFrames", C.c_int)]
 
 
 _host = None
@@ -118,6 +118,7 @@ def device_lib():
         L.ptss_live_counts.argtypes = [vp, _u32p, C.c_int, C.POINTER(C.c_int)]
         L.ptss_total_ray_bounces.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.ptss_frame_lanes.argtypes = [vp, C.POINTER(C.c_int)]
+        L.ptss_one_launch_frames.argtypes = [vp, C.POINTER(C.c_int)]
         L.ptss_guard_timeouts.argtypes = [vp, C.POINTER(C.c_uint)]
         L.ptss_bounce_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
         L.ptss_error_string.argtypes = [C.c_int]
@@ -219,7 +220,7 @@ class Renderer:
 
     def __init__(self, scene, width, height, max_iterations=15, seed=0x5EED, device=0, tile_rank=0, tile_world=1,
                  band_rows=8, sync_each_frame=True, float_accumulator=False, time_kernels=False, samples_per_pass=1,
-                 every_sphere_loop=False, frame_lanes=0, lanes_free_run=False):
+                 every_sphere_loop=False, frame_lanes=0, lanes_free_run=False, one_launch_frames=0):
         L = device_lib()
         cfg = RenderConfig()
         _check(L.ptss_default_config(C.byref(cfg)))
@@ -235,6 +236,7 @@ class Renderer:
         cfg.everySphereLoop = 1 if every_sphere_loop else 0
         cfg.frameLanes = frame_lanes
         cfg.lanesFreeRun = 1 if lanes_free_run else 0
+        cfg.oneLaunchFrames = one_launch_frames
         self.cfg = cfg
         self._scene = scene  # keep the arrays alive during create
         self._ctx = C.c_void_p()
@@ -354,6 +356,13 @@ class Renderer:
         v = C.c_ulonglong()
         _check(device_lib().ptss_total_ray_bounces(self._ctx, C.byref(v)))
         return v.value
+
+    @property
+    def one_launch_frames(self):
+        """True when this context traces a frame with ONE launch (cfg.oneLaunchFrames resolved for the current scene image)."""
+        v = C.c_int()
+        _check(device_lib().ptss_one_launch_frames(self._ctx, C.byref(v)))
+        return bool(v.value)
 
     @property
     def frame_lanes(self):

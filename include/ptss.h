@@ -24,8 +24,8 @@ extern "C" {
 #define PTSS_ENODEVICE (-3)/* no usable HIP device */
 #define PTSS_ENOMEM (-4)   /* host or device allocation failed */
 #define PTSS_ERANGE (-5)   /* output buffer too small / index out of range */
-#define PTSS_ETIMEOUT (-6) /* frame lanes only: a lane gave up waiting for a peer lane (a stream that did not run for ~2 s); the
-                              frame's loop guard was decided without the peer, so the buffers may hold a different image */
+#define PTSS_ETIMEOUT (-6) /* a bounded wait on the device (~2 s) expired: a frame lane for a peer lane, or a workgroup of the one-launch
+                              frame kernel for its shard; the frame was not traced as specified, the buffers may hold another image */
 #define PTSS_VERSION 300   /* what ptss_version() of a matching library returns; bumped whenever a struct below changes */
 
 typedef struct ptss_context ptss_context; /* ≙ ProgramData + RendererData + every cudaMalloc of main() */
@@ -74,6 +74,15 @@ typedef struct ptss_render_config {
      * nothing touches dev_pixels, the accumulator or the float sums on the device — or call ptss_synchronize() /
      * ptss_request_reset() first. */
     int lanesFreeRun;
+    /* One launch per frame, opt-in: a frame small enough for ALL its bounce-0 tiles to be resident on the device
+     * at once (up to about 3*2^17 rays per pass on an MI355X: 512x512 or 640x480 at one sample per tick) is traced by ONE kernel
+     * whose workgroups carry their shard from bounce to bounce, instead of one launch per bounce each at most one resident
+     * round wide: +7 % at 512x512. Same image, same counters. 1 = on where the frame qualifies (one lane, scene in LDS; a frame
+     * that does not qualify is traced bounce by bounce all the same); 0 (default) / -1 = off. Opt-in because the kernel's
+     * workgroups wait for each other: it must have the device to itself — two such kernels running at once (two contexts on
+     * two streams, or two processes sharing the GPU) can each hold slots the other needs; every wait is bounded (~2 s) and an
+     * expired one surfaces as PTSS_ETIMEOUT, but the frame is then lost. */
+    int oneLaunchFrames;
 } ptss_render_config;
 
 /* Fills the reference's defaults: 512x512 (DIM), maxIterations 15, seed 0x5EED, one tile, sync on. */
@@ -130,6 +139,8 @@ int ptss_total_ray_bounces(ptss_context* ctx, unsigned long long* out);
 /* HIP-event time of the bounce kernel since the last call (needs cfg.timeKernels): total ms, launches. */
 int ptss_bounce_kernel_time(ptss_context* ctx, double* total_ms, unsigned long long* launches);
 
+/* 1 when this context traces a frame with ONE launch (cfg.oneLaunchFrames resolved for the scene image in use). */
+int ptss_one_launch_frames(const ptss_context* ctx, int* out);
 /* Frame lanes this context runs (cfg.frameLanes resolved). */
 int ptss_frame_lanes(const ptss_context* ctx, int* out);
 /* How often a lane gave up waiting for a peer lane's live count (a stream that did not run for ~2 s): always 0 in a healthy

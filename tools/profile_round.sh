@@ -8,7 +8,10 @@
 # Run on the GPU box from the repo root:  tools/profile_round.sh r02 c3
 set -e
 tag=${1:-r02}; cfg=${2:-c3}; S=${3:-}
-sarg=""; [ -n "$S" ] && sarg="--samples-per-pass $S"
+# the PMC passes and the trace run a handful of steps: pin S to the configuration's default (or the one asked for), or bench.py
+# would pick another S for that step count and the counters would describe another launch size
+[ -z "$S" ] && S=$(python3 -c "import bench; print(bench.CONFIGS['$cfg']['samples'])")
+sarg="--samples-per-pass $S"
 out=gpurun_out/$tag/$cfg
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -25,5 +28,5 @@ S_used=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['confi
 python3 tools/pmc_summary.py $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_sq $out/pmc_mem > $out/summary.txt 2>&1
 python3 tools/pmc_counters.py $out $cfg $S_used > $out/pmc_counters.log 2>&1
 cp profiles/pmc_counters.json $out/pmc_counters.json
-python3 bench.py --config $cfg $sarg > $out/bench.json 2> $out/bench.err
+python3 bench.py --config $cfg > $out/bench.json 2> $out/bench.err   # the default run of that configuration (its default S is the one profiled)
 cat $out/bench.json
