@@ -227,3 +227,38 @@ def test_bounce_count_limits_in_a_mirror_box(bounces):
 @pytest.mark.parametrize("w,h,S", [(97, 53, 1), (1, 1, 1), (3, 1, 4), (131, 7, 2)])
 def test_frame_sizes_that_divide_by_nothing(w, h, S):
     check(ptss.Scene("mixed"), w, h, 3, ticks=2, S=S)
+
+
+def test_triangles_hit_at_exactly_the_same_distance_tie_like_the_reference():
+    """Bounded scenes store their triangles grouped by edge class (pttri.h) and visit them class by class; the reference's
+    sequential rule `dist <= distance` (Primitives.h:52) lets the LAST of several triangles hit at exactly the same distance win.
+    The closest hit keeps the key (distance, 0xFFFFFFFE - original index) instead. Exact ties made on purpose: every wall
+    triangle of a box appears two or three times with different materials — as an exact duplicate (same class, same arithmetic),
+    with its second and third vertex swapped (class (a, b) becomes (b, a): other products, the same plane), and rotated
+    (v1, v2, v0: general edges) — interleaved so that the winner by index is now an earlier, now a later stored position; a
+    sphere touching a wall and a light panel lying IN the ceiling's plane add sphere/triangle and triangle/triangle ties."""
+    X, Y, Z0, Z1 = 3.0, 2.5, 0.5, -7.0
+    walls = []
+    mats = [CREAM, RED, GREEN, MIRROR, PHONG, COOK]
+    corners = {
+        "floor": ((-X, -Y, Z0), (X, -Y, Z0), (X, -Y, Z1), (-X, -Y, Z1)),
+        "ceil": ((-X, Y, Z0), (-X, Y, Z1), (X, Y, Z1), (X, Y, Z0)),
+        "back": ((-X, -Y, Z1), (X, -Y, Z1), (X, Y, Z1), (-X, Y, Z1)),
+        "left": ((-X, -Y, Z0), (-X, -Y, Z1), (-X, Y, Z1), (-X, Y, Z0)),
+        "right": ((X, -Y, Z0), (X, Y, Z0), (X, Y, Z1), (X, -Y, Z1)),
+    }
+    tris = []
+    for k, (name, (p0, p1, p2, p3)) in enumerate(corners.items()):
+        for (a, b, c) in ((p0, p1, p2), (p0, p2, p3)):
+            tris.append((a, b, c, mats[k % len(mats)]))                 # the wall itself
+            tris.append((a, c, b, mats[(k + 1) % len(mats)]))           # second and third vertex swapped: the other class, the other facing
+            tris.append((a, b, c, mats[(k + 2) % len(mats)]))           # exact duplicate, later index
+            if k % 2 == 0:
+                tris.append((b, c, a, mats[(k + 3) % len(mats)]))       # rotated: one general edge
+    light = len(tris)
+    tris += quad((-1, Y, -2), (-1, Y, -4), (1, Y, -4), (1, Y, -2), EMIT)  # IN the ceiling's plane
+    tris += [(t[0], t[1], t[2], CREAM) for t in tris[:4]]                # the first wall once more, at the very end
+    spheres = [((0.0, -Y + 1.0, -4.0), 1.0, GLASS), ((-X + 0.75, 0.0, -3.0), 0.75, COOK), ((1.5, 0.5, -5.0), 0.8, MIRROR)]
+    s = build(spheres=spheres, triangles=tris, area=[((60, 60, 50), light)])
+    check(s, 96, 64, 6, ticks=3)
+    check(s, 64, 48, 5, ticks=2, S=3)
