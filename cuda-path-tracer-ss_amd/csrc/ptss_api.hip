@@ -273,7 +273,7 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     }
     // Storage order of the triangles: the caller's, or — SceneLayout::triClassed — grouped by edge class (pttri.h), the caller's
     // order kept inside a group. triOrder[position] = original index.
-    L.triClassed = (L.triDetBounded && L.sphereBounded) ? 1 : 0;
+    L.triClassed = (L.triDetBounded && L.sphereBounded && L.numTriangles <= 255) ? 1 : 0;   // (the class bounds travel as bytes)
     std::vector<int> triOrder((size_t)L.numTriangles), triCode((size_t)L.numTriangles, 0);
     for (int i = 0; i < L.numTriangles; ++i) {
         triOrder[(size_t)i] = i;
@@ -281,9 +281,10 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
         if (L.triClassed) triCode[(size_t)i] = pttri::triangleClass(t.vertex1 - t.vertex0, t.vertex2 - t.vertex0);   // the edges as stored below
     }
     std::stable_sort(triOrder.begin(), triOrder.end(), [&](int a, int b) { return triCode[(size_t)a] < triCode[(size_t)b]; });
-    for (int code = 0, pos = 0; code <= 16; ++code) {
+    for (int k = 0; k < 5; ++k) L.triClassPack[k] = 0u;
+    for (int code = 0, pos = 0; code <= 16 && L.triClassed; ++code) {
         while (pos < L.numTriangles && triCode[(size_t)triOrder[(size_t)pos]] < code) ++pos;
-        L.triClassBegin[code] = pos;
+        L.triClassPack[code / 4] |= (uint32_t)pos << (8 * (code % 4));
     }
     blob.assign((size_t)off + 1, float4{0, 0, 0, 0});
     ptq::build_thresholds(reinterpret_cast<float*>(&blob[L.offQuant]));

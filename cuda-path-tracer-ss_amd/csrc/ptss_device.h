@@ -112,11 +112,13 @@ struct SceneLayout {
     int triDetBounded;  // 1: every triangle has |e1| |e2| <= 2^100 (finite), so |det| = |e1 . (d x e2)| < 2^126 whenever
                         //    |d|^2 < 2^30 — the closest-hit triangle loop may then use the reciprocal's fast path unguarded
     int triClassed;     // 1: every vertex is finite (bounded geometry) and the triangles are STORED GROUPED BY EDGE CLASS (pttri.h; the
-                        //    caller's order inside a group): the uniform triangle loops run one loop per class, each with the body that
+                        //    caller's order inside a group; T <= 255): the uniform triangle loops run one loop per class, each with the body that
                         //    leaves out the products with that class's exact-zero edge components; the closest hit decides by the key
                         //    (distance, ~original index), which is what the reference's sequential `dist <= distance` rule ends on.
                         //    0: the caller's order, the general body, the sequential rule
-    int triClassBegin[17];  // positions [triClassBegin[c], triClassBegin[c + 1]) hold the triangles of class code c = class(e1) * 4 + class(e2)
+    uint32_t triClassPack[5];  // positions [begin(c), begin(c + 1)) hold the triangles of class code c = class(e1) * 4 + class(e2): the 17 begins
+                               // (begin(16) = T) as BYTES, four per word — five scalar registers instead of seventeen (classed scenes have
+                               // T <= 255); a loop header extracts its two bounds with two s_bfe (ptss_kernels.hip classBegin)
     int offTriPos;      // ints: stored position of each original triangle index
 };
 

@@ -262,7 +262,7 @@ __device__ __forceinline__ TriHit triangleTest(const TriRows& tr, vec3 o, vec3 d
 //     without divergence — but a scalar branch tree per triangle (35 scalar instructions, 9 branches) cost more than the
 //     shorter bodies saved (same-box A/B -2.5 %: scalar instructions are not free beside vector ones,
 //     tools/microbench/vgpr_banks.hip). So the host stores the triangles GROUPED BY CLASS (SceneLayout::triClassed /
-//     triClassBegin) and the loop becomes one loop per class: no dispatch at all. The visiting order is then no longer the
+//     triClassPack) and the loop becomes one loop per class: no dispatch at all. The visiting order is then no longer the
 //     caller's, which matters where the reference's sequential rule `dist <= distance` (Primitives.h:52) decides between two
 //     triangles hit at exactly the same distance: it ends on the HIGHEST index among them. kKeyed keeps (distance,
 //     0xFFFFFFFE - original index) as one 64-bit key — distances that pass `dist > 0` order like their bit patterns — and
@@ -310,16 +310,32 @@ __device__ __forceinline__ void triangleClassed(const float4* rows /* {v0, mat},
         best.w2 = hit ? b2 : best.w2;
     }
 }
-// One loop per edge class over the triangles stored for it (SceneLayout::triClassBegin); BODY(c1, c2, t) tests stored triangle t
+// One loop per edge class over the triangles stored for it; BODY(c1, c2, t) tests stored triangle t. The 17 class bounds travel
+// as bytes in five scalar registers (SceneLayout::triClassPack) and every loop header extracts its two with s_bfe: as seventeen
+// kernel-argument words the compiler evaluated all thirteen "is this class empty" conditions once per kernel, kept them as lane
+// masks, spilled those to VGPR lanes and read them back with two v_readlane per loop header — 26 per query. The empty asm
+// statements make the packed words opaque at each header, so that nothing about them is hoisted or kept.
+struct ClassBounds {
+    uint32_t w[5];
+};
+__device__ __forceinline__ ClassBounds classBounds(const SceneLayout& L) {
+    return ClassBounds{{L.triClassPack[0], L.triClassPack[1], L.triClassPack[2], L.triClassPack[3], L.triClassPack[4]}};
+}
+template <int kCode>
+__device__ __forceinline__ int classBegin(ClassBounds& b) {
+    asm volatile("" : "+s"(b.w[kCode / 4]));
+    return (int)((b.w[kCode / 4] >> (8 * (kCode % 4))) & 255u);
+}
 #define PTSS_FOR_TRIANGLES_BY_CLASS(L, BODY)                                                                        \
     do {                                                                                                            \
-        PTSS_TRI_CLASS_LOOP(L, 0, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 2, BODY) PTSS_TRI_CLASS_LOOP(L, 0, 3, BODY) \
-        PTSS_TRI_CLASS_LOOP(L, 1, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 1, 2, BODY) PTSS_TRI_CLASS_LOOP(L, 1, 3, BODY)      \
-        PTSS_TRI_CLASS_LOOP(L, 2, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 2, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 2, 3, BODY)      \
-        PTSS_TRI_CLASS_LOOP(L, 3, 0, BODY) PTSS_TRI_CLASS_LOOP(L, 3, 1, BODY) PTSS_TRI_CLASS_LOOP(L, 3, 2, BODY)      \
+        ClassBounds _cb = classBounds(L);                                                                           \
+        PTSS_TRI_CLASS_LOOP(_cb, 0, 0, BODY) PTSS_TRI_CLASS_LOOP(_cb, 0, 1, BODY) PTSS_TRI_CLASS_LOOP(_cb, 0, 2, BODY) PTSS_TRI_CLASS_LOOP(_cb, 0, 3, BODY) \
+        PTSS_TRI_CLASS_LOOP(_cb, 1, 0, BODY) PTSS_TRI_CLASS_LOOP(_cb, 1, 2, BODY) PTSS_TRI_CLASS_LOOP(_cb, 1, 3, BODY)      \
+        PTSS_TRI_CLASS_LOOP(_cb, 2, 0, BODY) PTSS_TRI_CLASS_LOOP(_cb, 2, 1, BODY) PTSS_TRI_CLASS_LOOP(_cb, 2, 3, BODY)      \
+        PTSS_TRI_CLASS_LOOP(_cb, 3, 0, BODY) PTSS_TRI_CLASS_LOOP(_cb, 3, 1, BODY) PTSS_TRI_CLASS_LOOP(_cb, 3, 2, BODY)      \
     } while (0)
-#define PTSS_TRI_CLASS_LOOP(L, c1, c2, BODY) \
-    for (int t = (L).triClassBegin[(c1) * 4 + (c2)]; t < (L).triClassBegin[(c1) * 4 + (c2) + 1]; ++t) { BODY(c1, c2, t) }
+#define PTSS_TRI_CLASS_LOOP(cb, c1, c2, BODY) \
+    for (int t = classBegin<(c1) * 4 + (c2)>(cb), tEnd = classBegin<(c1) * 4 + (c2) + 1>(cb); t < tEnd; ++t) { BODY(c1, c2, t) }
 
 // the any-hit form of the same bodies (lineOfSight is an OR over independent tests: any order)
 template <int kC1, int kC2>
