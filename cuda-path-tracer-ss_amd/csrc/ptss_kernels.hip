@@ -674,6 +674,9 @@ __device__ __forceinline__ uint32_t nthSetBit(uint32_t word, uint32_t r) {  // p
     return pos;
 }
 
+constexpr uint32_t kCandCap = 8 * kQueueCapConst + kQueueCapConst / 4 - 13 * 64;   // what the wave's LDS area holds behind the tables: 224 words
+static_assert(kCandCap >= 128, "the candidate queue must take a full trip after a drain");
+
 __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d,
                                                         bool live, Hit& h, uint32_t* ws) {
     const uint32_t lane = __lane_id();
@@ -681,9 +684,34 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
     uint32_t* bitsTab = ws + 6 * 64;                                                 // [4][64]
     uint32_t* startTab = ws + 10 * 64;                                               // [64]
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 11 * 64);  // [64]
+    uint32_t* candQ = ws + 13 * 64;                                                  // [kCandCap]: owner lane | sorted sphere position << 8
     const int* orig = reinterpret_cast<const int*>(cold + L.offSphereOrig);  // global memory (SceneLayout::ldsVec4)
     const int* posOf = reinterpret_cast<const int*>(cold + L.offSpherePos);
     const bool unitDir = ptm::abs(dot(d, d) - 1.0f) <= kAccelDirEps;
+    // CANDIDATES, second regrouping (round 3). A (ray, chunk) pair finds few candidates among its 16 spheres — the line of a
+    // ray that touches a chunk's bound meets 0.3 of the chunk's spheres on average — so resolving them where they are found
+    // (a per-lane loop inside every pass: as many trips as the busiest lane has candidates, a tenth of the lanes working) was
+    // the largest single piece of a mid-bounce launch (ablation builds, profiles/README.md). Instead every pass only APPENDS
+    // its candidates — (owner, sphere) words, ranked by ballot — to a queue in the wave's LDS area, and the queue is resolved
+    // 64 at a time with every lane busy: square root, roots, key, one LDS minimum into the owner's slot. Any order is fine
+    // (the merge is a minimum on (distance, ~original index)); the queue is drained whenever a trip might not fit, and at the
+    // end. (The shadow passes' regrouped part keeps resolving in place: the same queue there measured +-0 — a blocked segment
+    // leaves at its first hit, and most do.)
+    uint32_t candCount = 0;   // wave-uniform
+    auto resolveCandidates = [&](uint32_t n) {   // the last n <= 64 entries of the queue
+        const bool have = lane < n;
+        const uint32_t e = candQ[candCount - n + (have ? lane : 0u)];
+        const uint32_t owner = e & 63u;
+        const int pos = (int)(e >> 8);
+        const vec3 ro = v3(rayTab[0 * 64 + owner], rayTab[1 * 64 + owner], rayTab[2 * 64 + owner]);
+        const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
+        float t;
+        if (have && sphereTest(sc[L.offSphere + pos], ro, rd, ptm::inf(), t)) {
+            const uint32_t tb = (t != t) ? 0u : asU(t + 0.0f);
+            atomicMin(&best[owner], ((unsigned long long)tb << 32) | (unsigned long long)(0xffffffffu - (uint32_t)orig[pos]));
+        }
+        candCount -= n;
+    };
     rayTab[0 * 64 + lane] = o.x;
     rayTab[1 * 64 + lane] = o.y;
     rayTab[2 * 64 + lane] = o.z;
@@ -740,19 +768,24 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
             const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
             uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, ro, rd);
             if (!work) mask = 0;
-            unsigned long long key = ~0ull;
-            while (mask != 0) {
-                const int j = chunkSlot(__builtin_ctz(mask), chunk);
-                mask &= mask - 1;
-                float t;
-                if (sphereTest(sc[L.offSphere + base + j], ro, rd, ptm::inf(), t)) {
-                    const uint32_t tb = (t != t) ? 0u : asU(t + 0.0f);
-                    const unsigned long long k = ((unsigned long long)tb << 32) | (unsigned long long)(0xffffffffu - (uint32_t)orig[base + j]);
-                    key = k < key ? k : key;
+            while (waveAny(mask != 0)) {   // one trip per candidate of the busiest lane: append, do not resolve
+                if (candCount + 64u > kCandCap) {   // wave-uniform: make room first
+                    waveLdsFence();
+                    while (candCount >= 64u) resolveCandidates(64u);
+                    waveLdsFence();
                 }
+                const bool has = mask != 0;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const int j = chunkSlot(__builtin_ctz(mask), chunk);
+                    mask &= mask - 1;
+                    candQ[candCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = owner | ((uint32_t)(base + j) << 8);
+                }
+                candCount += (uint32_t)__popcll(m);
             }
-            if (key != ~0ull) atomicMin(&best[owner], key);
         }
+        waveLdsFence();
+        while (candCount != 0u) resolveCandidates(candCount < 64u ? candCount : 64u);
         waveLdsFence();
     }
     const unsigned long long won = best[lane];
