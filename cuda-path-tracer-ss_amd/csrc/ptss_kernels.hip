@@ -1993,7 +1993,7 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
 }
 
 template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairs>
-__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kFirst ? PTSS_MINWAVES_FIRST : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES))) void bounceKernel(  // chunked scenes: their LDS image caps occupancy near 5 anyway
+__global__ __launch_bounds__(kBlock, kAccel ? 4 : (kFirst ? PTSS_MINWAVES_FIRST : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES))) void bounceKernel(  // chunked scenes: their LDS image (21 KB + the work area) admits four workgroups per CU, so four waves per SIMD = 128 registers cost nothing (round 3: 5 -> 4, no scratch, c5 +2.8 %)
     FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int bounce, TileMap tile, EyeParams eye) {
     bounceBody<kLast, kSceneInLds, kFirst, kAccel, kBounded, kPairs>(fb, sceneBlob, L, bounce, tile, eye);
     // frame lanes: "this workgroup of bounce `bounce` has ended" (every workgroup, also one that had nothing to do) — the
@@ -2039,7 +2039,7 @@ __device__ __forceinline__ bool waitForCount(const uint32_t* word, uint32_t targ
 }
 
 template <bool kAccel, bool kBounded, bool kPairsWanted>
-__global__ __launch_bounds__(kBlock, kAccel ? 5 : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES)) void frameKernel(
+__global__ __launch_bounds__(kBlock, kAccel ? 4 : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES)) void frameKernel(
     FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int numBounces, TileMap tile, EyeParams eye) {
     extern __shared__ float4 lds[];
     constexpr bool kPairs = kPairsWanted && !kAccel;
