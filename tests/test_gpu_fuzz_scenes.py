@@ -110,3 +110,73 @@ def test_random_scene_matches_oracle(seed):
     assert np.array_equal(r.float_accumulator(), o.float_sum(), equal_nan=True)
     assert r.total_ray_bounces() == o.total_ray_bounces()
     r.close()
+
+
+def axis_scene(seed):
+    """Triangles whose edges are drawn from all the edge classes of pttri.h (along x, y or z; in a coordinate plane; general),
+    on a quarter-unit grid so that edges are shared, triangles coincide (exact distance ties) and rays graze edges and
+    corners — the cases in which the class forms of the kernels must give the general form's bits. Materials and spheres as
+    in random_scene; area lights sit on class triangles."""
+    scene, rng = random_scene(seed, nt=0)
+    d = scene.desc
+    nt = int(rng.integers(6, 40))
+    tri = (Triangle * nt)()
+
+    def edge(cls):
+        e = np.zeros(3)
+        if cls in (1, 2, 3):
+            e[cls - 1] = rng.choice([-1, 1]) * rng.integers(1, 17) * 0.25
+        elif cls == 4:                                               # in a coordinate plane: one exact zero (class 0 in the kernels)
+            e = rng.integers(-8, 9, 3) * 0.25
+            e[rng.integers(0, 3)] = 0.0
+        else:
+            e = rng.normal(0, 1.5, 3)
+        if rng.random() < 0.2:
+            e = np.where(e == 0.0, -0.0, e)                            # negative zeros are zeros too
+        return e
+    i = 0
+    while i < nt:
+        base = rng.integers(-12, 13, 3) * 0.25 + np.array([0, 0, -4.0])
+        e1, e2 = edge(int(rng.integers(0, 6))), edge(int(rng.integers(0, 6)))
+        copies = 2 if (rng.random() < 0.25 and i + 1 < nt) else 1    # the same triangle twice: an exact tie, lowest original index wins
+        for _ in range(copies):
+            _set3(tri[i].vertex0, base)
+            _set3(tri[i].vertex1, base + e1)
+            _set3(tri[i].vertex2, base + e2)
+            for n in (tri[i].normal0, tri[i].normal1, tri[i].normal2):
+                _set3(n, rng.normal(0, 1, 3))
+            tri[i].materialIdx = int(rng.integers(0, d.numMaterials))
+            i += 1
+    na = int(rng.integers(0, 3))
+    al = (AreaLight * max(na, 1))()
+    for k in range(na):
+        _set3(al[k].power, rng.random(3) * 80)
+        al[k].area, al[k].triangleIdx, al[k].numTriangles = 1.0, int(rng.integers(0, nt - 1)), 2
+    d.triangles, d.numTriangles = tri, nt
+    d.areaLights, d.numAreaLights = (al if na else None), na
+    scene.keep = scene.keep + (tri, al)
+    return scene, rng
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_axis_aligned_triangle_scene_matches_oracle(seed):
+    scene, rng = axis_scene(5000 + seed)
+    w, h = int(rng.integers(48, 128)), int(rng.integers(32, 80))
+    bounces, S = int(rng.integers(2, 10)), int(rng.choice([1, 2, 4]))
+    r = ptss.Renderer(scene, w, h, max_iterations=bounces, float_accumulator=True, samples_per_pass=S, seed=seed * 104729 + 3)
+    o = oracle.Oracle(scene.desc, w, h, max_iterations=bounces, samples_per_pass=S, seed=seed * 104729 + 3)
+    cam = ptss.default_camera()
+    for tick in range(3):
+        if tick == 1:                                                # an axis-parallel view from a grid point: rays along edges and through corners
+            cam.position.x, cam.position.y, cam.position.z = 0.25, -0.5, 1.0
+            r.set_camera(cam)
+            o.set_camera(cam)
+        r.generate_frame()
+        o.generate_frame()
+        assert np.array_equal(r.live_counts(), o.live_counts()), (seed, tick)
+    assert np.array_equal(r.accumulator(), o.accumulator())
+    assert np.array_equal(r.pixels(), o.pixels())
+    assert np.array_equal(r.float_accumulator(), o.float_sum(), equal_nan=True)
+    assert r.total_ray_bounces() == o.total_ray_bounces()
+    r.close()
+    o.close()
