@@ -55,7 +55,7 @@ __device__ __forceinline__ void diagCull(const float4* sc, const SceneLayout& L,
             const float4 b = sc[L.offChunk + g + q];
             const vec3 v = o - xyz(b);
             const float dv = dot(d, v), vv = dot(v, v), a = -dv - T;
-            const bool ahead = unitDir && (a > 0.0f) && ((a * a) * (1.0f - 2e-5f) > b.w + kAccelMu * vv);
+            const bool ahead = unitDir && (a > 0.0f) && ((a * a) * (1.0f - 2e-5f) > (1.0f - kAccelMu) * b.w + kAccelMu * vv);
             rev |= ahead ? 0u : (1u << q);
         }
         touched += (uint32_t)__builtin_popcount(bits);

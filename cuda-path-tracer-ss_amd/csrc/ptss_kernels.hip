@@ -550,19 +550,22 @@ struct Hit {
 constexpr int kQueueCapConst = 2 * 64;  // = kQueueCap (static_assert below): segments per wave queue plane
 constexpr float kAccelMu = 5e-3f + 5e-3f * 5e-3f;   // m + m^2
 constexpr float kAccelDirEps = 1e-5f;               // | |d|^2 - 1 | up to which a direction counts as unit
-constexpr float kAccelDvScale = 1.0f + 2e-5f;       // 1 / (1 - eps) rounded up
+constexpr float kAccelQ = 0.25f * (1.0f + 2e-5f) / (1.0f - kAccelMu) * (1.0f + 1e-6f);   // (1 + 2 eps) / (4 (1 - mu)), rounded up
 
 // One chunk bound's verdict ("this lane's ray may touch the chunk") shifted into `rev` through the carry, as shiftInSphere does
-// for spheres. The verdict is assembled from three direct compares as wave masks (scalar and / or / not) and handed to
-// v_addc as its carry-in SGPR pair: no v_cndmask, no v_or, no v_mov for the bit.
+// for spheres. ONE test (derivation: packScene): with t = dv - |dv| = 2 min(dv, 0) — exact, no compare, no select —
+// vv - kAccelQ t^2 is (a lower bound of) the squared distance of the chunk's centre from the RAY, the half line t >= 0: the
+// line's distance while the closest approach lies ahead of the origin, the origin's own distance once it lies behind. The
+// chunk is skipped when that exceeds the stored bound; the compare's wave mask is handed to v_addc as its carry-in SGPR
+// pair: no v_cndmask, no v_or, no v_mov for the bit. (Until round 3 the line and a separate "wholly behind the origin's
+// plane" test — two more compares, a multiply, an fma and three scalar instructions per bound, and a looser verdict: a ray
+// leaving a chunk it starts beside was still sent into it.)
 __device__ __forceinline__ void shiftInChunk(uint32_t& rev, float4 b, vec3 o, vec3 d) {
     const vec3 v = o - xyz(b);
     const float dv = dot(d, v);
     const float vv = dot(v, v);
-    const float dv2 = dv * dv;
-    const unsigned long long lineClear = maskOf((vv * (1.0f - kAccelMu) - kAccelDvScale * dv2) > b.w);   // the LINE misses the chunk
-    const unsigned long long behind = maskOf(dv > 0.0f) & maskOf(dv2 * (1.0f - 2e-5f) > b.w + kAccelMu * vv);  // it lies behind the origin
-    const unsigned long long may = ~(lineClear | behind);  // not provably out of reach (a NaN lands here too)
+    const float t = dv - ptm::abs(dv);
+    const unsigned long long may = ~maskOf(ptm::fma(-kAccelQ, t * t, vv) > b.w);   // not provably out of reach (a NaN lands here too)
     asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(rev) : "s"(may) : "vcc");
 }
 // four bounds per trip (one address, immediate offsets; the host pads the bound rows to a multiple of four and the padding's
