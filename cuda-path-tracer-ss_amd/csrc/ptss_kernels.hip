@@ -654,10 +654,12 @@ __device__ __forceinline__ bool anySphereChunked(const float4* sc, const SceneLa
 
 // ---- The same traversal with the work REGROUPED across the wave. In a dense scene an incoherent ray touches 30-50 chunks
 // and the counts differ widely between lanes: walking them lane by lane keeps 34 % of the lanes busy
-// (tools/stress_counters.sh). Here every lane publishes its ray and its chunk bits in the wave's LDS area, an exclusive
-// scan of the counts numbers all (ray, chunk) pairs of the wave, and each pass hands 64 consecutive pairs to the 64 lanes:
-// lane l finds the owner of pair q by bisection over the scan, the chunk as the owner's r-th set bit, tests the chunk's
+// (tools/stress_counters.sh). Here every lane publishes its ray in the wave's LDS area, an exclusive scan of the chunk
+// counts numbers all (ray, chunk) pairs of the wave, every lane writes its pairs into a list at its scan position, and
+// each pass hands 64 consecutive pairs to the 64 lanes: lane l reads pair q = (owner, chunk), tests the chunk's
 // spheres against the OWNER's ray, and folds what it finds into the owner's slot with one 64-bit LDS minimum on the key
+// (the shadow passes' regrouped part, anySpheresHybrid, still FINDS pair q: owner by bisection over the scan, chunk as the
+// owner's r-th set bit — its tables sit in strided half planes of the segment queue)
 // (distance bits, ~original index): minimum distance first, highest original index among equals — the order-free form
 // of the reference's sequential rule (distances are >= 0 here, so their bit patterns order like the values; -0 counts as
 // +0, all-NaN rays tie on the distance and end on the highest index, as the sequential loop does). The owner finally
@@ -677,6 +679,7 @@ __device__ __forceinline__ uint32_t nthSetBit(uint32_t word, uint32_t r) {  // p
     return pos;
 }
 
+constexpr uint32_t kPairCap = 2 * 5 * 64;   // 16-bit words in the five 64-word tables between the rays and the keys
 constexpr uint32_t kCandCap = 8 * kQueueCapConst + kQueueCapConst / 4 - 13 * 64;   // what the wave's LDS area holds behind the tables: 224 words
 static_assert(kCandCap >= 128, "the candidate queue must take a full trip after a drain");
 
@@ -684,8 +687,7 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
                                                         bool live, Hit& h, uint32_t* ws) {
     const uint32_t lane = __lane_id();
     float* rayTab = reinterpret_cast<float*>(ws);                                    // [6][64]
-    uint32_t* bitsTab = ws + 6 * 64;                                                 // [4][64]
-    uint32_t* startTab = ws + 10 * 64;                                               // [64]
+    uint16_t* pairQ = reinterpret_cast<uint16_t*>(ws + 6 * 64);                      // [kPairCap]: owner lane | chunk (of this group of 128) << 6
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 11 * 64);  // [64]
     uint32_t* candQ = ws + 13 * 64;                                                  // [kCandCap]: owner lane | sorted sphere position << 8
     const int* orig = reinterpret_cast<const int*>(cold + L.offSphereOrig);  // global memory (SceneLayout::ldsVec4)
@@ -723,69 +725,65 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
     rayTab[5 * 64 + lane] = d.z;
     best[lane] = ~0ull;
     for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
-        const ChunkBits mine = chunkBits128(sc, L, g0, o, d, unitDir, live);
-        uint32_t cnt = 0;
+        ChunkBits mine = chunkBits128(sc, L, g0, o, d, unitDir, live);
+        // PAIRS. Every lane writes its (owner lane, chunk) pairs — 16-bit words, ascending chunks — into the wave's pair list
+        // at the position an exclusive scan of the counts gives it; a pass then reads one word per lane. (Until round 3 a pass
+        // FOUND its pairs: bisection over the scan for the owner, the owner's four bit words, the r-th set bit — 120 vector
+        // instructions and eleven dependent LDS round trips per pass; the expansion is one loop per 128 chunks with as many
+        // trips as the busiest lane has chunks.) A list holds kPairCap pairs; what does not fit stays in the lanes' bits for
+        // the next round.
+        for (;;) {
+            const uint32_t cnt = (uint32_t)(__builtin_popcount(mine.w[0]) + __builtin_popcount(mine.w[1]) + __builtin_popcount(mine.w[2]) +
+                                            __builtin_popcount(mine.w[3]));
+            uint32_t incl = cnt;  // inclusive scan over the lanes
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bitsTab[q * 64 + lane] = mine.w[q];
-            cnt += (uint32_t)__builtin_popcount(mine.w[q]);
-        }
-        uint32_t incl = cnt;  // inclusive scan over the lanes
-#pragma unroll
-        for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint32_t below = (uint32_t)__shfl_up((int)incl, off);
-            incl += (lane >= off) ? below : 0u;
-        }
-        startTab[lane] = incl - cnt;
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63);  // wave-uniform
-        waveLdsFence();
-        for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            const bool have = q < total;
-            uint32_t lo = 0, hi = 64;  // owner = the last lane whose start <= q (its count is then > 0)
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const bool right = startTab[mid] <= q;
-                lo = right ? mid : lo;
-                hi = right ? hi : mid;
+            for (uint32_t off = 1; off < 64; off <<= 1) {
+                const uint32_t below = (uint32_t)__shfl_up((int)incl, off);
+                incl += (lane >= off) ? below : 0u;
             }
-            const uint32_t owner = have ? lo : lane;
-            uint32_t r = have ? q - startTab[owner] : 0u;
-            uint32_t word = 0, wordIdx = 0;
-            bool found = false;
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);  // wave-uniform
+            if (total == 0u) break;
+            uint32_t pos = incl - cnt;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const uint32_t bits = bitsTab[w * 64 + owner];
-                const uint32_t pc = (uint32_t)__builtin_popcount(bits);
-                const bool here = !found && r < pc;
-                word = here ? bits : word;
-                wordIdx = here ? (uint32_t)w : wordIdx;
-                found = found || here;
-                r -= (!found) ? pc : 0u;
-            }
-            const bool work = have && found;
-            const int chunk = g0 + (int)(32u * wordIdx + nthSetBit(word, r));
-            const int base = (work ? chunk : 0) * kChunkSpheres;
-            const vec3 ro = v3(rayTab[0 * 64 + owner], rayTab[1 * 64 + owner], rayTab[2 * 64 + owner]);
-            const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
-            uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, ro, rd);
-            if (!work) mask = 0;
-            while (waveAny(mask != 0)) {   // one trip per candidate of the busiest lane: append, do not resolve
-                if (candCount + 64u > kCandCap) {   // wave-uniform: make room first
-                    waveLdsFence();
-                    while (candCount >= 64u) resolveCandidates(64u);
-                    waveLdsFence();
+                while (waveAny(mine.w[w] != 0u && pos < kPairCap)) {
+                    if (mine.w[w] != 0u && pos < kPairCap) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(mine.w[w]);
+                        mine.w[w] &= mine.w[w] - 1u;
+                        pairQ[pos++] = (uint16_t)(lane | ((32u * (uint32_t)w + k) << 6));
+                    }
                 }
-                const bool has = mask != 0;
-                const unsigned long long m = __ballot(has);
-                if (has) {
-                    const int j = chunkSlot(__builtin_ctz(mask), chunk);
-                    mask &= mask - 1;
-                    candQ[candCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = owner | ((uint32_t)(base + j) << 8);
-                }
-                candCount += (uint32_t)__popcll(m);
             }
+            const uint32_t n = total < kPairCap ? total : kPairCap;
+            waveLdsFence();
+            for (uint32_t q0 = 0; q0 < n; q0 += 64) {
+                const bool work = q0 + lane < n;
+                const uint32_t e = pairQ[work ? q0 + lane : 0u];
+                const uint32_t owner = e & 63u;
+                const int chunk = g0 + (int)(e >> 6);
+                const int base = chunk * kChunkSpheres;
+                const vec3 ro = v3(rayTab[0 * 64 + owner], rayTab[1 * 64 + owner], rayTab[2 * 64 + owner]);
+                const vec3 rd = v3(rayTab[3 * 64 + owner], rayTab[4 * 64 + owner], rayTab[5 * 64 + owner]);
+                uint32_t mask = chunkCandidates(sc + L.offSphere, base, chunk, ro, rd);
+                if (!work) mask = 0;
+                while (waveAny(mask != 0)) {   // one trip per candidate of the busiest lane: append, do not resolve
+                    if (candCount + 64u > kCandCap) {   // wave-uniform: make room first
+                        waveLdsFence();
+                        while (candCount >= 64u) resolveCandidates(64u);
+                        waveLdsFence();
+                    }
+                    const bool has = mask != 0;
+                    const unsigned long long m = __ballot(has);
+                    if (has) {
+                        const int j = chunkSlot(__builtin_ctz(mask), chunk);
+                        mask &= mask - 1;
+                        candQ[candCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = owner | ((uint32_t)(base + j) << 8);
+                    }
+                    candCount += (uint32_t)__popcll(m);
+                }
+            }
+            waveLdsFence();
+            if (total <= kPairCap) break;
         }
         waveLdsFence();
         while (candCount != 0u) resolveCandidates(candCount < 64u ? candCount : 64u);

@@ -7,7 +7,10 @@ length + the float error of b*b - 4c)? CPU only, numpy; the kd split is restated
 Result (round 3): mid-bounce rays (origins on sphere surfaces, uniform directions) touch 5.09 sphere bounds; boxes with the same
 margin 5.04 (-1 %), with a margin no analysis could justify (m = 3e-4) 4.23 (-17 %); camera rays 6.97 / 5.88 / 5.38. A box test
 costs ~25 instructions per bound against 18 (line-box separating axes d x e_k plus the behind-the-origin test; no reciprocal), and
-every lane tests all 64 bounds: +450 instructions per query against at most 0.85 x 800 saved in visits. Not built."""
+every lane tests all 64 bounds: +450 instructions per query against at most 0.85 x 800 saved in visits. Not built.
+
+Built instead (second half of round 3; the last lines this tool prints): the distance of the bound's centre from the RAY (one test,
+vv - min(dv, 0)^2: 4.67), near-minimal enclosing balls as bounds (3.95; with the leaves improved pair by pair in packScene: 3.73)."""
 import os
 import sys
 import numpy as np
@@ -70,3 +73,23 @@ W=200
 x=(rng.random(N)-0.5)*2; y=(rng.random(N)-0.5)*2*9/16
 dc=np.stack([x,y,-np.ones(N)],1); dc/=np.linalg.norm(dc,axis=1,keepdims=True)
 stats(np.zeros((N,3)),dc,'camera rays')
+
+
+# ---- what was built instead: the RAY's distance, and near-minimal enclosing balls (csrc/ptss_api.hip enclosingBall) -------------
+def ball(l):
+    l = np.array(l); c = P[l].mean(0); rbest = 1e30; cbest = c
+    for it in range(1, 513):
+        dist = np.linalg.norm(P[l] - c, axis=1) + R[l]
+        j = int(np.argmax(dist))
+        if dist[j] < rbest: rbest, cbest = dist[j], c.copy()
+        dirv = P[l][j] - c
+        c = c + dirv / max(np.linalg.norm(dirv), 1e-30) * dist[j] / (it + 1)
+    return cbest, rbest
+balls = [ball(l) for l in leaves]
+C2 = np.array([c for c, r in balls]); R2 = np.array([r for c, r in balls])
+mu = m + m * m
+for label, CC, RR in (("mean centres", C, Rb), ("near-minimal balls", C2, R2)):
+    v = o[:, None, :] - CC[None]; dv = (v * dd[:, None, :]).sum(2); vv = (v * v).sum(2)
+    dvm = np.minimum(dv, 0)
+    ray = ~((vv * (1 - mu) - (1 + 2e-5) * dvm * dvm) > RR ** 2 * (1 + m) ** 3)
+    print("surface rays, distance from the RAY, %s: %.2f bounds per ray (mean radius %.3f)" % (label, ray.sum(1).mean(), RR.mean()))
