@@ -586,17 +586,35 @@ __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec
 
 #include "ptss_diag.h"
 
-// Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): the spheres are visited
-// from position (chunk mod kChunkSpheres) on, wrapping, so that the 16-byte gathers of a wave spread over the LDS banks;
-// verdicts enter through the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit
-// of that mask back into the sphere's slot inside the chunk. The traversal is order-free (ties go by original index).
+// Candidate mask of ONE chunk for a lane that gathers its own rows (lanes sit in different chunks): visit i reads slot
+// i ^ (chunk mod kChunkSpheres), so that the 16-byte gathers of a wave spread over the LDS banks; verdicts enter through
+// the carry (shiftInSphere), so visit i lands in bit kChunkSpheres - 1 - i. chunkSlot() turns a bit of that mask back into
+// the sphere's slot inside the chunk. The traversal is order-free (ties go by original index). Where the image is staged in
+// LDS and the sphere rows start on a 256-byte boundary (they do: packScene puts them first, the dynamic LDS is aligned), a
+// row's address is (chunk's address ^ (chunk mod 16) << 4) ^ (i << 4): ONE v_xor with a constant per row instead of add, and,
+// shift-add (round 3; -2 of 16 instructions per sphere).
+typedef __attribute__((address_space(3))) const float4 LdsRow;
 __device__ __forceinline__ uint32_t chunkCandidates(const float4* spheres /* sc + L.offSphere */, int base, int chunk, vec3 o, vec3 d) {
+    static_assert(kChunkSpheres * sizeof(float4) <= 256, "a chunk's rows must not straddle the 256-byte window the XOR walks");
     uint32_t rev = 0;
+    const int twist = chunk & (kChunkSpheres - 1);
+#if __HIP_DEVICE_COMPILE__   // (the host pass of this file only parses device functions; it has no LDS address space)
+    if (__builtin_amdgcn_is_shared(spheres)) {   // decided at compile time wherever the image's address space is known
+        const uint32_t first = (uint32_t)(uintptr_t)(LdsRow*)spheres;
+        if ((first & 255u) == 0u) {   // wave-uniform
+            uint32_t x = (first + (uint32_t)base * (uint32_t)sizeof(float4)) ^ ((uint32_t)twist << 4);
+            asm volatile("" : "+v"(x));   // keep it one value: the compiler would re-associate it into (i ^ twist) << 4 ^ base per row
+#pragma unroll
+            for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere<true>(rev, *(LdsRow*)(uintptr_t)(x ^ ((uint32_t)i << 4)), o, d);
+            return rev;
+        }
+    }
+#endif
 #pragma unroll 4
-    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere<true>(rev, spheres[base + ((i + chunk) & (kChunkSpheres - 1))], o, d);
+    for (int i = 0; i < kChunkSpheres; ++i) shiftInSphere<true>(rev, spheres[base + (i ^ twist)], o, d);
     return rev;
 }
-__device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSpheres - 1 - bit) + chunk) & (kChunkSpheres - 1); }
+__device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSpheres - 1 - bit) ^ chunk) & (kChunkSpheres - 1); }
 
 // The chunk bits of up to 128 chunks (4 words) are gathered first and walked in ONE per-lane loop: the wave then runs as
 // long as its busiest lane's TOTAL, not the sum over 32-chunk groups of each group's busiest lane.
@@ -1944,7 +1962,7 @@ __device__ __forceinline__ void bounceTile(const FrameBuffers& fb, const SceneLa
 template <bool kLast, bool kSceneInLds, bool kFirst, bool kAccel, bool kBounded, bool kPairsWanted>
 __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4* __restrict__ sceneBlob, const SceneLayout& L, int bounce,
                                            const TileMap& tile, const EyeParams& eye) {
-    extern __shared__ float4 lds[];
+    extern __shared__ __attribute__((aligned(256))) float4 lds[];
     constexpr bool kPairs = kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
@@ -2042,7 +2060,7 @@ __device__ __forceinline__ bool waitForCount(const uint32_t* word, uint32_t targ
 template <bool kAccel, bool kBounded, bool kPairsWanted>
 __global__ __launch_bounds__(kBlock, kAccel ? 4 : (kBounded ? PTSS_MINWAVES_BOUNDED : PTSS_MINWAVES)) void frameKernel(
     FrameBuffers fb, const float4* __restrict__ sceneBlob, SceneLayout L, int numBounces, TileMap tile, EyeParams eye) {
-    extern __shared__ float4 lds[];
+    extern __shared__ __attribute__((aligned(256))) float4 lds[];
     constexpr bool kPairs = kPairsWanted && !kAccel;
     if (fb.frameRays <= fb.minLive) return;   // loop guard at bounce 0: the frame starts with <= 128 rays
     const uint32_t shard = blockIdx.x % kShards, myTile = blockIdx.x / kShards;
