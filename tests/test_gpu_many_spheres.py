@@ -131,3 +131,26 @@ def test_camera_outside_the_structures_range_falls_back():
 def test_stress_preset_switches_and_agrees():
     scene = ptss.Scene("stress")                         # BASELINE.json configs[5]: 1,024 spheres
     run_pair(scene, 80, 45, 6, ticks=2, S=2)
+
+
+def test_camera_inside_the_cluster_rays_leaving_chunks_they_start_beside():
+    """The chunk test is on the distance from the RAY (the half line), so a ray that starts beside or inside a chunk's bound
+    and leaves it skips the chunk: with the camera in the middle of the 1,024 spheres every primary ray has most bounds
+    behind it and many around it. Against the oracle at a small size, against the every-sphere loop at a larger one."""
+    scene = ptss.Scene("stress")
+    cam = ptss.default_camera()
+    for pos in ((0.3, 0.2, -4.5), (-1.7, 1.1, -6.0), (2.4, -2.2, -2.6)):
+        cam.position.x, cam.position.y, cam.position.z = pos
+        run_pair(scene, 72, 40, 8, ticks=1, S=2, camera=cam)
+
+    def frames(every_sphere_loop):
+        r = ptss.Renderer(scene, 640, 360, max_iterations=12, sync_each_frame=False, samples_per_pass=2, every_sphere_loop=every_sphere_loop)
+        r.set_camera(cam)
+        for _ in range(2):
+            r.generate_frame()
+        out = (r.accumulator(), r.live_counts().copy(), r.total_ray_bounces())
+        r.close()
+        return out
+    on, off = frames(False), frames(True)
+    assert np.array_equal(on[1], off[1]) and on[2] == off[2]
+    assert np.array_equal(on[0], off[0])
