@@ -827,7 +827,7 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
 // the wave's queue planes that the current pass does not read (tab[plane] = that half of plane `plane`), which is why
 // the caller uses this only for a pass whose other half is free.
 // chunks of 16 in kd order, configs[4]'s scene at S = 4, same box: 0: 4,571, 1: 4,589, 2: 4,597-4,605, 3: 4,585, 4: 4,535,
-// 8: 4,270, 16: 4,189 Mrays/s
+// 8: 4,270, 16: 4,189 Mrays/s; again with round 3's tighter bounds: 0: 5,866, 1: 5,901, 2: 5,931, 3: 5,835, 4: 5,738
 constexpr int kWarmChunks = 2;
 
 __device__ __forceinline__ bool anySpheresHybrid(const float4* sc, const SceneLayout& L, const float* seg, float* tab, vec3 lo,
