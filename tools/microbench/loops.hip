@@ -3,6 +3,11 @@
 // per VALU instruction the SIMD can issue? Includes the product's kernel source, so every -D build switch applies:
 //   hipcc <build.py HIP_FLAGS> -I include -I cuda-path-tracer-ss_amd/csrc [-DPTSS_...] tools/microbench/loops.hip -o loops
 // Measurement tool only: never built by build.py, never loaded by the product or the tests.
+// HISTORICAL: written against round 2's kernel source (git show c7be1ea:cuda-path-tracer-ss_amd/csrc/ptss_kernels.hip). Round 3
+// pruned the functions and switches it calls (sphereMayHit, triangleTest, PTSS_SPHERE_UNROLL, PTSS_ROW128) and stores the
+// triangles grouped by edge class, so it does not compile against the present source; its numbers are the round-2 ones quoted
+// in profiles/README.md and DESIGN.md §6. Round 3's loop measurements are counter-based instead (tools/valu_per_wave.py,
+// tools/pmc_counters.py, the ablation builds a1/a2/a3 of tools/build_variants.py).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
