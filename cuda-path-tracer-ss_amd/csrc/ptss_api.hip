@@ -674,6 +674,11 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         // hardware queues and serialise. (With the lanes coupled through stream events the gain at 1280x720 was inside the noise.)
         // All of that is the FREE-RUNNING mode (cfg.lanesFreeRun); ordered strictly on the caller's stream — a fork and a join per
         // frame — two lanes ran at 13,180 against one lane's 13,800, so the library's own choice is then one lane.
+        // Round 3, wide passes again (tools/lanes_large.py, interleaved, twice): 3840x2160 S = 4, 12 bounces, 1,024 spheres (33 M rays per
+        // pass, the late bounces a hundredth of that) 5,958-5,970 / 6,077; 1920x1080 S = 40 (83 M) 18,273-18,294 / 18,420-18,454: a second
+        // lane is worth +2.0 % / +0.8 % there. The rule stays at 2^24 all the same: a caller who wants it asks for frameLanes = 2; by
+        // default a wide pass keeps one lane, one set of pools (the second doubles 5-16 GB) and launches that do not overlap, so that
+        // a kernel's duration means the same in a profile and in ptss_bounce_kernel_time.
         if (numLanes == 0) numLanes = (cfg->lanesFreeRun && rays >= (3ull << 17) && rays <= (1ull << 24)) ? 2 : 1;
     }
     c->lanes.resize((size_t)numLanes);
