@@ -16,7 +16,9 @@ BASELINE.json `configs`):
   c2            configs[1]: 1280x720, preset "lambert" (the default scene's 36 primitives, every non-emissive material
                 Lambert), 8 bounces, 512 spp: default 16 steps x 1 pass x S = 32
   c5            configs[4]: 3840x2160, preset "stress" (1,024 spheres + open Cornell box), 12 bounces; the config asks for
-                4096 spp on 8 GPUs — one GPU runs 64 spp of that very frame here (16 steps x 1 pass x S = 4; a rate metric)
+                4096 spp on 8 GPUs — one GPU runs 128 spp of that very frame here (8 steps x 1 pass x S = 16; a rate metric).
+                S = 16 since the end of round 3: 133 M rays per pass keep the late bounces' launches wide (S = 4: 5,900,
+                8: 6,210, 16: 6,450 Mrays/s; the library takes < 226 M rays per pass)
 
 For N > 1 the SAME frame is sharded by interleaved 8-row bands across the ranks (north_star: pixel-tile shard),
 so total work is fixed ("strong" scaling); the integer accumulators are gathered to rank 0 with one
@@ -57,7 +59,7 @@ CONFIGS = {
                what="36 primitives (20 spheres, 16 triangles), Lambert only"),
     "c3": dict(index=2, width=1920, height=1080, bounces=8, preset="mixed", spp=2000, run_spp=2000, samples=40, steps=50, s_range=(16, 64),
                what="22 spheres, 16 triangles, Lambert/Phong/Cook-Torrance/glass/mirror"),
-    "c5": dict(index=4, width=3840, height=2160, bounces=12, preset="stress", spp=4096, run_spp=64, samples=4, steps=16, s_range=(4, 4),
+    "c5": dict(index=4, width=3840, height=2160, bounces=12, preset="stress", spp=4096, run_spp=128, samples=16, steps=8, s_range=(16, 16),
                what="1,024 random spheres + 12 triangles, all material classes (stream-compaction stress)"),
 }
 

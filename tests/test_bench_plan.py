@@ -20,9 +20,9 @@ def test_other_configs_keep_their_sample_lanes():
     assert bench.plan_steps(bench.CONFIGS["c2"]) == (16, 1, 32)
     K, P, S = bench.plan_steps(bench.CONFIGS["c2"], 20)
     assert K * P * S >= 512 and 16 <= S <= 64
-    for k in (None, 1, 7, 20, 64):                             # the 4K / 1,024-sphere frame: S stays 4 (S x 8.3 M rays per pass)
+    for k in (None, 1, 7, 20, 64):                             # the 4K / 1,024-sphere frame: S stays 16 (S x 8.3 M rays per pass; the library takes < 226 M)
         K, P, S = bench.plan_steps(bench.CONFIGS["c5"], k)
-        assert S == 4 and K * P * S >= 64
+        assert S == 16 and K * P * S >= 128
 
 
 def test_moved_bytes_per_ray_bounce():
