@@ -1,5 +1,5 @@
 """tools/fuzz_parity.py [count=100] [first_seed=20000] — a longer run of the two scene fuzzers of tests/test_gpu_fuzz_scenes.py
-(random records; axis-class triangles on a grid) against the oracle on one GPU: prints one line per mismatch and a total.
+(random records; axis-class triangles on a grid; 64-600 random spheres for the chunked traversal) against the oracle on one GPU: prints one line per mismatch and a total.
 Test infrastructure (it calls the oracle); not part of the product."""
 import os
 import sys
@@ -18,7 +18,11 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 bad = 0
 for k in range(count):
     seed = first + k
-    scene, rng = (axis_scene if k % 2 else random_scene)(seed)
+    kind = ("random", "axis", "many-sphere")[k % 3]
+    if kind == "many-sphere":   # 64..600 spheres: the chunked traversal (kd leaves, enclosing balls, ray-distance bound test, regrouped visits)
+        scene, rng = random_scene(seed, ns=64 + (seed * 7919) % 537)
+    else:
+        scene, rng = (axis_scene if kind == "axis" else random_scene)(seed)
     w, h = int(rng.integers(32, 112)), int(rng.integers(24, 72))
     bounces, S = int(rng.integers(1, 10)), int(rng.choice([1, 2, 3]))
     one = int(rng.integers(0, 2))
@@ -33,7 +37,7 @@ for k in range(count):
     ok = ok and r.total_ray_bounces() == o.total_ray_bounces() and r.guard_timeouts() == 0
     if not ok:
         bad += 1
-        print("MISMATCH seed %d (%s) %dx%d bounces %d S %d one-launch %d" % (seed, "axis" if k % 2 else "random", w, h, bounces, S, one), flush=True)
+        print("MISMATCH seed %d (%s) %dx%d bounces %d S %d one-launch %d" % (seed, kind, w, h, bounces, S, one), flush=True)
     if k % 20 == 19:
         print("%d scenes, %d mismatches" % (k + 1, bad), flush=True)
     r.close()
