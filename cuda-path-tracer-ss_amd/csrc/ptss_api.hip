@@ -336,8 +336,9 @@ void packScene(const ptss_scene_desc& s, ptss::SceneLayout& L, std::vector<float
     L.offAreaLight = off;   off += 2 * L.numAreaLights;
     L.offTriPos = off;      off += (L.numTriangles + 3) / 4;   // ints: stored position of each original triangle index
     L.offQuant = off;       off += ptq::kTableFloats / 4;
-    L.offPrimSphere = off;  off += accel ? 0 : sphereAlloc;  // the chunked traversal has no camera-origin shortcut
+    L.offPrimSphere = off;  off += accel ? 0 : sphereAlloc;  // the chunked traversal keeps the camera-origin parts of its chunk bounds only (offPrimChunk)
     L.offPrimTri = off;     off += 2 * L.numTriangles;
+    L.offPrimChunk = off;   off += accel ? (L.numChunks + 3) / 4 * 4 : 0;
     L.ldsVec4 = off;        // everything up to here is staged into LDS
     if (accel) {            // cold integer tables of the many-sphere image: global memory only
         L.offSphereMat = off;   off += (sphereRows + 3) / 4;

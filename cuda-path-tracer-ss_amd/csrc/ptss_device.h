@@ -99,6 +99,7 @@ struct SceneLayout {
     int offQuant;       // 65 rows: the 8-bit tone-map thresholds T[0..256] (ptquant.h), read by finishPath
     int offPrimSphere;  // S x {o - centre, dot(v,v) - r^2}        written on the device per camera (primaryPrepKernel)
     int offPrimTri;     // T x 2: {o - v0, dot(e2, r)}, {r = cross(s, e1), 0}
+    int offPrimChunk;   // many-sphere image: numChunks x {o - C, dot(v,v) - bound, rounded down}, per camera as well (bounce 0's chunk test)
     int totalVec4;
     int ldsVec4;        // rows [0, ldsVec4) are staged into LDS; the rest (the many-sphere integer tables: material, original
                         // index, position — read only when a hit is accepted) stay in global memory

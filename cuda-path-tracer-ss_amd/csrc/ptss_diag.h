@@ -48,7 +48,7 @@ __device__ __forceinline__ void diagCull(const float4* sc, const SceneLayout& L,
     uint32_t touched = 0, needed = 0;
     for (int g = 0; g < L.numChunks && g < 128; g += 32) {
         const int left = L.numChunks - g;
-        const uint32_t bits = live ? chunkMask(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
+        const uint32_t bits = live ? chunkMask<false>(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
         uint32_t rev = 0;
         const int trips = ((left < 32 ? left : 32) + 3) >> 2;
         for (int q = 0; q < 4 * trips; ++q) {

@@ -568,17 +568,34 @@ __device__ __forceinline__ void shiftInChunk(uint32_t& rev, float4 b, vec3 o, ve
     const unsigned long long may = ~maskOf(ptm::fma(-kAccelQ, t * t, vv) > b.w);   // not provably out of reach (a NaN lands here too)
     asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(rev) : "s"(may) : "vcc");
 }
+// The same for a ray that starts at the camera (bounce 0): the row holds v = o - C and vv - bound, evaluated once per camera by
+// primaryPrepKernel with the very same subtraction (the difference rounded DOWN: it can only keep a chunk) — 8 instructions
+// instead of 14 per bound.
+__device__ __forceinline__ void shiftInChunkPrimary(uint32_t& rev, float4 pv, vec3 d) {
+    const float dv = dot(d, xyz(pv));
+    const float t = dv - ptm::abs(dv);
+    const unsigned long long may = ~maskOf(ptm::fma(-kAccelQ, t * t, pv.w) > 0.0f);
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(rev) : "s"(may) : "vcc");
+}
 // four bounds per trip (one address, immediate offsets; the host pads the bound rows to a multiple of four and the padding's
 // bits are dropped here)
+template <bool kPrimary>
 __device__ __forceinline__ uint32_t chunkMask(const float4* bounds, int cnt, vec3 o, vec3 d, bool unitDir) {
     const int trips = (cnt + 3) >> 2;  // wave-uniform, 1..8
     uint32_t rev = 0;
     for (int g = 0; g < trips; ++g) {
         const float4 b0 = bounds[4 * g], b1 = bounds[4 * g + 1], b2 = bounds[4 * g + 2], b3 = bounds[4 * g + 3];
-        shiftInChunk(rev, b0, o, d);
-        shiftInChunk(rev, b1, o, d);
-        shiftInChunk(rev, b2, o, d);
-        shiftInChunk(rev, b3, o, d);
+        if constexpr (kPrimary) {
+            shiftInChunkPrimary(rev, b0, d);
+            shiftInChunkPrimary(rev, b1, d);
+            shiftInChunkPrimary(rev, b2, d);
+            shiftInChunkPrimary(rev, b3, d);
+        } else {
+            shiftInChunk(rev, b0, o, d);
+            shiftInChunk(rev, b1, o, d);
+            shiftInChunk(rev, b2, o, d);
+            shiftInChunk(rev, b3, o, d);
+        }
     }
     const uint32_t all = (cnt >= 32) ? 0xffffffffu : ((1u << cnt) - 1u);
     return unitDir ? ((__builtin_bitreverse32(rev) >> (32 - 4 * trips)) & all) : all;
@@ -621,13 +638,14 @@ __device__ __forceinline__ int chunkSlot(int bit, int chunk) { return ((kChunkSp
 struct ChunkBits {
     uint32_t w[4];
 };
+template <bool kPrimary = false>
 __device__ __forceinline__ ChunkBits chunkBits128(const float4* sc, const SceneLayout& L, int g0, vec3 o, vec3 d, bool unitDir, bool live) {
     ChunkBits b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int g = g0 + 32 * q;
         const int left = L.numChunks - g;  // wave-uniform
-        b.w[q] = (left > 0) ? chunkMask(sc + L.offChunk + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
+        b.w[q] = (left > 0) ? chunkMask<kPrimary>(sc + (kPrimary ? L.offPrimChunk : L.offChunk) + g, left < 32 ? left : 32, o, d, unitDir) : 0u;
         if (!live) b.w[q] = 0u;
     }
     return b;
@@ -701,6 +719,7 @@ constexpr uint32_t kPairCap = 2 * 5 * 64;   // 16-bit words in the five 64-word 
 constexpr uint32_t kCandCap = 8 * kQueueCapConst + kQueueCapConst / 4 - 13 * 64;   // what the wave's LDS area holds behind the tables: 224 words
 static_assert(kCandCap >= 128, "the candidate queue must take a full trip after a drain");
 
+template <bool kPrimary>
 __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const float4* cold, const SceneLayout& L, vec3 o, vec3 d,
                                                         bool live, Hit& h, uint32_t* ws) {
     const uint32_t lane = __lane_id();
@@ -743,7 +762,7 @@ __device__ __forceinline__ void closestSpheresRegrouped(const float4* sc, const 
     rayTab[5 * 64 + lane] = d.z;
     best[lane] = ~0ull;
     for (int g0 = 0; g0 < L.numChunks; g0 += 128) {
-        ChunkBits mine = chunkBits128(sc, L, g0, o, d, unitDir, live);
+        ChunkBits mine = chunkBits128<kPrimary>(sc, L, g0, o, d, unitDir, live);
         // PAIRS. Every lane writes its (owner lane, chunk) pairs — 16-bit words, ascending chunks — into the wave's pair list
         // at the position an exclusive scan of the counts gives it; a pass then reads one word per lane. (Until round 3 a pass
         // FOUND its pairs: bisection over the scan for the owner, the owner's four bit words, the r-th set bit — 120 vector
@@ -937,7 +956,7 @@ __device__ __forceinline__ Hit closestHit(const float4* sc, const float4* cold, 
     h.kind = 0;
     h.idx = 0;
     h.w0 = h.w1 = h.w2 = 0;
-    if constexpr (kAccel) closestSpheresRegrouped(sc, cold, L, o, d, live, h, ws);
+    if constexpr (kAccel) closestSpheresRegrouped<kPrimary>(sc, cold, L, o, d, live, h, ws);
     for (int base = 0; base < (kAccel ? 0 : L.numSpheres); base += 32) {
         const int cnt = (L.numSpheres - base < 32) ? (L.numSpheres - base) : 32;
         uint32_t mask = sphereCandidates<kPrimary, kBounded>(sc + (kPrimary ? L.offPrimSphere : L.offSphere) + base, cnt, o, d);
@@ -1598,6 +1617,12 @@ __global__ void primaryPrepKernel(float4* __restrict__ blob, SceneLayout L, vec3
         const vec3 v = origin - xyz(sp);
         blob[L.offPrimSphere + i] = float4{v.x, v.y, v.z, dot(v, v) - sp.w};
     }
+    if (L.accelSpheres && i < L.numChunks) {   // the chunk test's origin part (shiftInChunkPrimary)
+        const float4 b = blob[L.offChunk + i];
+        const vec3 v = origin - xyz(b);
+        const float x = dot(v, v) - b.w;
+        blob[L.offPrimChunk + i] = float4{v.x, v.y, v.z, x - ptm::abs(x) * 2.4e-7f};   // down by more than an ulp
+    }
     if (i < L.numTriangles) {
         const vec3 v0 = xyz(blob[L.offTri + 3 * i]), e1 = xyz(blob[L.offTri + 3 * i + 1]), e2 = xyz(blob[L.offTri + 3 * i + 2]);
         const vec3 s = origin - v0;
@@ -1707,7 +1732,7 @@ __device__ __forceinline__ void bounceTile(const FrameBuffers& fb, const SceneLa
         h.kind = 2; h.idx = (int)(pixOf(ray.pix) % (uint32_t)L.numTriangles); h.distance = 1.0f + ray.d.x;
         h.w0 = 0.3f; h.w1 = 0.3f; h.w2 = 0.4f;
 #else
-        const Hit h = closestHit<kFirst && !kAccel, kAccel, kBounded>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
+        const Hit h = closestHit<kFirst, kAccel, kBounded>(sc, sceneBlob, L, ray.o, ray.d, valid, reinterpret_cast<uint32_t*>(wq));
 #endif
         const bool hit = valid && h.kind != 0;
         if constexpr (!kFirst) {
