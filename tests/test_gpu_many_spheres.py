@@ -61,6 +61,18 @@ def test_large_random_scenes(seed, ns, nt):
     run_pair(scene, int(rng.integers(48, 100)), int(rng.integers(27, 60)), int(rng.integers(3, 9)), S=int(rng.choice([1, 3])), seed=seed)
 
 
+@pytest.mark.parametrize("seed,ns", [(7101, 2300), (7102, 4500)])
+def test_more_than_128_chunks(seed, ns):
+    """Beyond 2,048 spheres the chunk bits come in batches of 128 chunks (four words per lane and batch), and the image no longer
+    fits the LDS next to the work area: the kernels read it in place. Pair lists, camera-origin bound rows and the leaf
+    refinement all see several batches here."""
+    scene, rng = random_scene(seed, ns=ns, nt=8)
+    run_pair(scene, 56, 32, 5, ticks=2, S=2, seed=seed)
+    on = run_pair(scene, 40, 24, 4, ticks=1, seed=seed + 1)
+    off = run_pair(scene, 40, 24, 4, ticks=1, seed=seed + 1, every_sphere_loop=True)
+    assert np.array_equal(on, off)
+
+
 def test_giant_wall_spheres_among_many_small_ones():
     """A smallpt-style room (walls = spheres of radius 1e5: chunk bounds a hundred thousand units wide, discriminants that
     cancel to b^2) filled with 90 small spheres: the chunked traversal and its shorter sphere test against the oracle."""
