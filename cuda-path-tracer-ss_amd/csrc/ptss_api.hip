@@ -110,8 +110,6 @@ struct ptss_context {
     bool usePathTracer = true;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     float lastMs = 0.0f;
-    int classSplitMode = 1;
-    bool classSplit = false;   // FrameBuffers::classSplit: the scene refracts and the frame is traced bounce by bounce (ptss_create)
     bool oneLaunch = false, oneLaunchAlt = false;   // the frame is traced by ONE launch (frameKernel) with the current / the alternate scene image
     int gridCap = 0;             // workgroups per shard at most = 16 resident rounds of this scene's bounce kernel (0 = uncapped)
     bool sceneInLds = true;      // scene staged in LDS (true) or read through scalar loads (false)
@@ -492,7 +490,6 @@ ptss::FrameBuffers frameBuffers(const ptss_context* c, int laneIdx, ptss_uchar4*
     fb.quantTable = reinterpret_cast<const float*>(c->dScene + c->layout.offQuant);
     fb.pixels = pixels;
     fb.regionCap = ln.regionCap;
-    fb.classSplit = c->classSplit ? 3u : 0u;   // per launch: ptss_generate_frame
     fb.numPixels = c->numPixels;
     fb.plane = c->capacity;
     fb.samples = c->samples;
@@ -686,21 +683,6 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         if (numLanes == 0) numLanes = (cfg->lanesFreeRun && rays >= (3ull << 17) && rays <= (1ull << 24)) ? 2 : 1;
     }
     c->lanes.resize((size_t)numLanes);
-    // Scenes with many spheres get the chunked image (see accelEligible / packScene); cfg.everySphereLoop keeps the plain one
-    const bool wantAccel = accelEligible(*scene) && !cfg->everySphereLoop;
-    std::vector<float4> blob, blobAlt;
-    packScene(*scene, c->layout, blob, wantAccel);
-    if (wantAccel) packScene(*scene, c->layoutAlt, blobAlt, false);
-    c->haveAccel = c->accelActive = wantAccel;
-    // Class split (ptss_device.h FrameBuffers::classSplit): scenes with a refractive material, traced bounce by bounce (the one-launch
-    // frame's workgroups wait for their own shard only) by the kernels that carry it (not the paired-segment ones of mostly
-    // diffuse scenes, SceneLayout::neePairs). A region then takes the survivors of two, so it is twice as large.
-    for (size_t i = 0; i < scene->numMaterials; ++i)
-        if (scene->materials[i].refrAvg > 0.0f) c->classSplit = true;
-    if (cfg->oneLaunchFrames > 0 || c->layout.neePairs) c->classSplit = false;
-#ifdef PTSS_TUNING_KNOBS
-    if (const char* e = getenv("PTSS_CLASS_SPLIT")) { c->classSplit = c->classSplit && atoi(e) != 0; c->classSplitMode = atoi(e); }
-#endif
     uint32_t shardCount0[ptss::kMaxLanes][ptss::kShards] = {{0}};
     {
         // bounce 0 walks S sample planes of `capacity` pixels (capacity = numPixels rounded up to a tile); tile t belongs
@@ -710,8 +692,8 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         const uint32_t rounds = (tiles + ptss::kShards - 1) / ptss::kShards;
         for (int k = 0; k < numLanes; ++k) {
             const uint32_t laneRounds = (rounds + (uint32_t)numLanes - 1 - (uint32_t)k) / (uint32_t)numLanes;
-            c->lanes[(size_t)k].regionCap = (laneRounds ? laneRounds : 1) * ptss::kBlock * (c->classSplit ? 2u : 1u);
-            c->lanes[(size_t)k].maxBlocks = (int)(laneRounds ? laneRounds : 1) * ptss::kShards;   // bounce 0's tiles; a fuller region is walked grid-stride
+            c->lanes[(size_t)k].regionCap = (laneRounds ? laneRounds : 1) * ptss::kBlock;
+            c->lanes[(size_t)k].maxBlocks = (int)(c->lanes[(size_t)k].regionCap / ptss::kBlock) * ptss::kShards;
         }
         for (uint32_t t = 0; t < tiles; ++t) {
             const uint32_t first = (t % tilesPerPlane) * ptss::kBlock;  // first pixel of the tile inside its plane
@@ -721,6 +703,12 @@ int ptss_create(const ptss_scene_desc* scene, const ptss_render_config* cfg, pts
         }
     }
 
+    // Scenes with many spheres get the chunked image (see accelEligible / packScene); cfg.everySphereLoop keeps the plain one
+    const bool wantAccel = accelEligible(*scene) && !cfg->everySphereLoop;
+    std::vector<float4> blob, blobAlt;
+    packScene(*scene, c->layout, blob, wantAccel);
+    if (wantAccel) packScene(*scene, c->layoutAlt, blobAlt, false);
+    c->haveAccel = c->accelActive = wantAccel;
     // Scenes whose image fits the default 64 KiB dynamic-LDS window are staged in LDS; larger ones are read in place
     // (wave-uniform scalar loads + per-lane gathers from global memory) — same kernel, same results, no size limit.
     const bool sceneFitsLds = ptss::bounceLdsBytes(c->layout, true) <= 64 * 1024;
@@ -1036,10 +1024,6 @@ int ptss_generate_frame(ptss_context* c, ptss_uchar4* pixels, int ticks) {
             if (i > 0)
                 for (int j = 0, p = 0; j < K; ++j)
                     if (j != k) fbs[k].peerTarget[p++] = c->lanes[(size_t)j].doneTarget[i - 1];
-            // class split: bit 0 = the regions are walked pair by pair, bit 1 = this launch sorts its survivors into the pair's two regions
-            // — every bounce but the one that feeds the LAST: that one tone-maps every ray it holds, and gains more from rays left in
-            // pixel order than from unlit rays set apart (measured, profiles/README.md)
-            if (c->classSplit) fbs[k].classSplit = 1u | ((i + 2 < numIterations || c->classSplitMode == 6) ? 2u : 0u);
             HIP_TRY(ptss::launchBounce(ls, fbs[k], c->dScene, c->layout, i, i == numIterations - 1, c->sceneInLds, bounded, blocks, c->tile, eye));
             ln.doneTarget[i] += (uint32_t)blocks;  // every workgroup of the launch adds 1 to done[i][its shard] as it ends
             if (c->cfg.timeKernels) {

@@ -15,7 +15,7 @@ namespace ptss {
 // region s only and own the s-th live-ray counter, so the compaction atomics of one launch are spread over kShards
 // addresses (one address sustains only ~88 returning atomics/us on MI355X — measured: a single counter was a 45 ps/ray
 // serial floor, profiles/README.md). A region's survivors can never outnumber its input, so regionCap =
-// ceil(tiles / kShards) * kBlock always suffices (twice that with FrameBuffers::classSplit, where a region takes from two). Inside a region the rays of one tile (kBlock consecutive slots) form a
+// ceil(tiles / kShards) * kBlock always suffices. Inside a region the rays of one tile (kBlock consecutive slots) form a
 // BLOCK of kRayPlanes planes of kBlock words: word (slot, plane p) = ((slot / kBlock) * kRayPlanes + p) * kBlock +
 // slot % kBlock. Lane i of a wave touches word i of a plane — 256-B contiguous wave accesses — and a plane's offset
 // inside the block is a compile-time constant (addressing: ptss_kernels.hip, tileBlock / slotWord).
@@ -68,14 +68,9 @@ constexpr int kBlock = PTSS_BLOCK;          // rays per tile = threads per workg
 constexpr int kChunkSpheres = PTSS_CHUNK;
 static_assert((kChunkSpheres & (kChunkSpheres - 1)) == 0, "chunk size must be a power of two");   // spheres per chunk of the many-sphere traversal
 constexpr int kShards = PTSS_SHARDS;        // pool regions / live-ray counters per bounce
-static_assert(kShards % 2 == 0 && kShards <= 64, "the class split halves the shards; frameKernel gives each shard a lane of one wave");
 constexpr int kCountStride = 32;            // one counter per 128-B line
 constexpr int kCountWords = (kMaxBounces + 1) * kShards * kCountStride;
 __host__ __device__ inline int countIndex(int bounce, int shard) { return (bounce * kShards + shard) * kCountStride; }
-// Where shard s's region lies in a pool: the lower-half shard p and its class-split partner kShards / 2 + p side by side (regions 2 p
-// and 2 p + 1), so that a wave can store survivors of both classes with ONE scalar base and 32-bit lane offsets (ptss_create bounds
-// two regions' bytes below 2^32).
-__host__ __device__ inline uint32_t regionOf(uint32_t shard) { return shard < (uint32_t)(kShards / 2) ? 2u * shard : 2u * (shard - (uint32_t)(kShards / 2)) + 1u; }
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kMinLiveRays = 128;  // loop guard `numRays > 128`, CudaTracer.cu:622
 
@@ -174,10 +169,6 @@ struct FrameBuffers {
     uint32_t* staged;        // S > 1 only: this pass's sample of every stream, x | y << 8 | z << 16 (one plane per sample lane)
     ptss_uchar4* pixels;     // display buffer or nullptr
     uint32_t regionCap;      // slots per shard region (a multiple of kBlock); a region is regionCap * kRayPlanes words
-    uint32_t classSplit;     // 1: a workgroup of shard s writes the survivors that stay OUTSIDE spheres to shard s % (kShards / 2) and those that
-                             // head INTO the sphere they hit to shard kShards / 2 + s % (kShards / 2) (regions twice the unsplit size: a region
-                             // then takes from two); 0: every survivor stays in shard s. Same rays, same results — a ray carries its pixel and
-                             // its random stream — only their grouping into waves differs
     uint32_t numPixels;      // local pixels
     uint32_t plane;          // numPixels rounded up to kBlock: stride of the per-pixel planes (one plane per sample lane)
     uint32_t samples;        // S = cfg.samplesPerPass: independent random streams per pixel traced per pass

@@ -1666,9 +1666,7 @@ struct TileEnv {
     const float4* sceneBlob;   // ... in global memory (the many-sphere image's cold integer tables)
     const float* quantT;
     const float* in;           // this shard's region of the input pool
-    float* out;                // ... of the output pool (class split: of shard shardA; shardB's region follows it, ptss_device.h regionOf)
-    uint32_t shardA, shardB;   // whose counters of the next bounce the survivors are added to (no split: both this shard)
-    bool split;                // FrameBuffers::classSplit
+    float* out;                // ... of the output pool
     float* wq;                 // this wave's LDS queue
     uint32_t* wqOwner;
     unsigned char* wqAnswer;
@@ -1965,32 +1963,17 @@ __device__ __forceinline__ void bounceTile(const FrameBuffers& fb, const SceneLa
         // writeToPixelsKernel for the paths that ended. Each wave compacts on its own — 64-bit ballot, popcount lane rank, ONE
         // returning atomic per wave on the shard's counter (16 counters share the load) — no barrier; the atomic is issued
         // first so that its round trip hides behind the tone-mapping of the finished lanes.
-        // Class split (FrameBuffers::classSplit): a survivor that heads INTO the sphere it has just hit — refracted in, or reflected
-        // on the inside — meets that sphere's inside next: unlit (no shade(), :166), refraction or total reflection. Those rays go
-        // to regions of their own, so that next bounce their waves skip next-event estimation as a whole and the lit rays' waves
-        // do not carry them through it as idle lanes. Which region a ray travels in changes no value: it carries its pixel and
-        // its random stream.
+        uint32_t slot = 0;
         if constexpr (!kLast) {
-            // (not in the paired-segment kernels: their scenes are four fifths diffuse, SceneLayout::neePairs, and ptss_create leaves the split off)
-            const bool toB = !kPairs && env.split && alive && h.kind == 1 && dot(ray.d, normal) < 0.0f;
-            const bool toA = alive && !toB;
-            const unsigned long long liveA = __ballot(toA), liveB = __ballot(toB);
-            if (liveA | liveB) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const int leaderA = liveA ? __ffsll((long long)liveA) - 1 : 0, leaderB = liveB ? __ffsll((long long)liveB) - 1 : 0;
+            const unsigned long long live = __ballot(alive);
+            if (live) {
+                const int leader = __ffsll((long long)live) - 1;
                 uint32_t base0 = 0;
-                if (liveA != 0ull && (int)lane == leaderA)
-                    base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)env.shardA)], (uint32_t)__popcll(liveA));
-                if (liveB != 0ull && (int)lane == leaderB)
-                    base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)env.shardB)], (uint32_t)__popcll(liveB));
-                // consumed after the finish work below
+                if ((int)lane == leader)
+                    base0 = atomicAdd(&fb.counts[countIndex(bounce + 1, (int)shard)], (uint32_t)__popcll(live));
+                slot = base0;  // consumed after the finish work below
                 if (valid && !alive && !(PTSS_ABLATE & 8)) finishPath(fb, ray, quantT);
-                // one store per plane for both classes: shardB's region follows shardA's, so a lane's class only moves its 32-bit offset
-                uint32_t slot = __shfl(base0, leaderA) + __popcll(liveA & below);
-                if (liveB != 0ull) {
-                    const uint32_t slotB = __shfl(base0, leaderB) + __popcll(liveB & below) + fb.regionCap;
-                    slot = toB ? slotB : slot;
-                }
+                slot = __shfl(slot, leader) + __popcll(live & ((1ull << lane) - 1ull));
                 if (alive) storeRay<kCoherentIo>(out, slot, ray);
             } else if (valid && !(PTSS_ABLATE & 8)) {
                 finishPath(fb, ray, quantT);
@@ -2006,24 +1989,14 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
                                            const TileMap& tile, const EyeParams& eye) {
     extern __shared__ __attribute__((aligned(256))) float4 lds[];
     constexpr bool kPairs = kPairsWanted && !kAccel;   // the two shadow segments of a surface point travel and are tested together (SceneLayout::neePairs)
-    // Which region(s) this workgroup walks. Without the class split: shard s = blockIdx % kShards, tiles blockIdx / kShards, + grid / kShards, ...
-    // With it (FrameBuffers::classSplit) the two regions of a PAIR — shard p = blockIdx % (kShards / 2), which holds the rays that travel
-    // outside spheres, and shard kShards / 2 + p, which holds those inside — are walked as ONE list of tiles by the pair's workgroups,
-    // because the two are unequal (and a launch whose even workgroups carry seventeen tiles and whose odd ones four runs at the
-    // pace of half the machine: measured, profiles/README.md). The pair is also what its survivors are written back to.
-    const bool split = !kFirst && (fb.classSplit & 1u) != 0u;
-    const uint32_t group = split ? kShards / 2 : kShards;       // workgroups with equal blockIdx % group share a tile list
-    const uint32_t shard = blockIdx.x % group;
+    const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = fb.counts[countIndex(bounce, (int)shard)];  // this shard's live rays (of this lane)
-    const uint32_t nUpper = split ? fb.counts[countIndex(bounce, (int)(kShards / 2 + shard))] : 0u;
-    const uint32_t tilesLower = (n + kBlock - 1) / kBlock, tilesUpper = (nUpper + kBlock - 1) / kBlock;
     if constexpr (kFirst) {
         if (fb.frameRays <= fb.minLive) return;  // loop guard, CudaTracer.cu:622: the frame starts with <= 128 rays
     } else {
-        if (blockIdx.x / group >= tilesLower + tilesUpper) return;  // nothing of this shard reached this bounce (whatever the guard says), or no
-                                                                    // tile of it for this workgroup: the grid is sized by the fullest shard
-        if (n + nUpper <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
-            uint32_t own = 0;            // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
+        if (n == 0) return;  // nothing of this shard reached this bounce (whatever the guard says)
+        if (n <= fb.minLive) {  // loop guard on the FRAME's live count (device-side; every workgroup that has work reaches
+            uint32_t own = 0;   // the same verdict). Only a nearly empty shard has to add up; only a nearly empty LANE asks its peers.
             for (int s = 0; s < kShards; ++s) own += fb.counts[countIndex(bounce, s)];
             if (own <= fb.minLive && frameLiveCount(fb, bounce, own, fb.peerTarget) <= fb.minLive) return;
         }
@@ -2047,30 +2020,19 @@ __device__ __forceinline__ void bounceBody(const FrameBuffers& fb, const float4*
     const float* quantT = reinterpret_cast<const float*>(sc + L.offQuant);
 
     const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
-    const float* __restrict__ in = fb.pool[bounce & 1] + regionOf(shard) * regionWords;  // this shard's region
+    const float* __restrict__ in = fb.pool[bounce & 1] + shard * regionWords;  // this shard's region
+    float* __restrict__ out = fb.pool[(bounce + 1) & 1] + shard * regionWords;
     const int numLights = L.numPointLights + L.numAreaLights;
-    // where the survivors go: bounce 0 (every shard has frame tiles) starts the split, every later bounce keeps its pair
-    const bool splitOut = (fb.classSplit & 2u) != 0u;   // (not for the last bounce's input: ptss_api.hip)
-    const uint32_t shardA = (fb.classSplit & 1u) ? blockIdx.x % (kShards / 2) : shard, shardB = splitOut ? kShards / 2 + shardA : shardA;
-    TileEnv env{sc, sceneBlob, quantT, in, fb.pool[(bounce + 1) & 1] + regionOf(shardA) * regionWords,
-                shardA, shardB, splitOut, wq, wqOwner, wqAnswer, kFirst ? blockIdx.x % kShards : shard, lane, n, numLights, bounce};
+    const TileEnv env{sc, sceneBlob, quantT, in, out, wq, wqOwner, wqAnswer, shard, lane, n, numLights, bounce};
 
     // one tile per workgroup when the host's grid hint is right; grid-stride keeps any n correct
     // bounce 0 walks the FRAME's tiles (S sample planes of fb.plane pixels; tile t belongs to shard t % kShards),
-    // every later bounce walks the shard's compacted region (the pair's two regions, one after the other, with the class split)
+    // every later bounce walks the shard's compacted region
     // (with frame lanes: round R of the frame belongs to lane R % laneCount, whose round R / laneCount it is)
-    if constexpr (kFirst) {
-        const uint32_t roundsOfShard = (fb.firstTiles + kShards - 1 - env.shard) / kShards;
-        const uint32_t span = ((roundsOfShard + fb.laneCount - 1 - fb.laneIndex) / fb.laneCount) * kBlock;
-        for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock)
-            bounceTile<kLast, kFirst, kAccel, kBounded, kPairs, false>(fb, L, tile, eye, env, base);
-    } else {
-        for (uint32_t t = blockIdx.x / group; t < tilesLower + tilesUpper; t += gridDim.x / group) {
-            const bool upper = t >= tilesLower;   // wave-uniform
-            env.in = in + (upper ? regionWords : (size_t)0);   // the partner's region is the next one (regionOf)
-            env.n = upper ? nUpper : n;
-            bounceTile<kLast, kFirst, kAccel, kBounded, kPairs, false>(fb, L, tile, eye, env, (upper ? t - tilesLower : t) * kBlock);
-        }
+    const uint32_t roundsOfShard = (fb.firstTiles + kShards - 1 - shard) / kShards;
+    const uint32_t span = kFirst ? ((roundsOfShard + fb.laneCount - 1 - fb.laneIndex) / fb.laneCount) * kBlock : n;
+    for (uint32_t base = (blockIdx.x / kShards) * kBlock; base < span; base += (gridDim.x / kShards) * kBlock) {
+        bounceTile<kLast, kFirst, kAccel, kBounded, kPairs, false>(fb, L, tile, eye, env, base);
     }
 }
 
@@ -2140,8 +2102,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 4 : (kBounded ? PTSS_MINWAVES_BOUN
     for (int k = threadIdx.x; k < L.ldsVec4; k += kBlock) lds[k] = sceneBlob[k];   // the scene, once per frame
     __syncthreads();
     const size_t regionWords = (size_t)fb.regionCap * kRayPlanes;
-    TileEnv env{lds, sceneBlob, reinterpret_cast<const float*>(lds + L.offQuant), nullptr, nullptr, shard, shard, false /* a workgroup waits for its OWN shard only */,
-                wq, wqOwner, wqAnswer, shard, lane, 0u,
+    TileEnv env{lds, sceneBlob, reinterpret_cast<const float*>(lds + L.offQuant), nullptr, nullptr, wq, wqOwner, wqAnswer, shard, lane, 0u,
                 L.numPointLights + L.numAreaLights, 0};
     uint32_t tilesNow = rounds, raysNow = 0;
     // the guard's view of the other shards (lanes 0..15 of wave 0, one shard each): the next bounce to verify, -1 = that shard is empty
@@ -2150,8 +2111,8 @@ __global__ __launch_bounds__(kBlock, kAccel ? 4 : (kBounded ? PTSS_MINWAVES_BOUN
         const bool last = b == numBounces - 1;
         env.bounce = b;
         env.n = raysNow;
-        env.in = fb.pool[b & 1] + regionOf(shard) * regionWords;
-        env.out = fb.pool[(b + 1) & 1] + regionOf(shard) * regionWords;
+        env.in = fb.pool[b & 1] + shard * regionWords;
+        env.out = fb.pool[(b + 1) & 1] + shard * regionWords;
         const uint32_t base = myTile * kBlock;
         if (b == 0) {
             if (last) bounceTile<true, true, kAccel, kBounded, kPairs, true>(fb, L, tile, eye, env, base);
@@ -2210,7 +2171,7 @@ __global__ __launch_bounds__(kBlock, kAccel ? 4 : (kBounded ? PTSS_MINWAVES_BOUN
                 }
                 uint32_t total = theirs;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) total += (uint32_t)__shfl_xor((int)total, off);   // lanes >= kShards hold 0
+                for (int off = 8; off >= 1; off >>= 1) total += (uint32_t)__shfl_xor((int)total, off);
                 const bool allOk = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
                 if (lane == 0) {
                     if (!allOk) atomicAdd(fb.guardTimeouts, 1u);
@@ -2285,7 +2246,7 @@ __global__ void flushKernel(FrameBuffers fb, int numBounces, FlushTargets target
             n = n < blockDim.x ? n : blockDim.x;
             if (i < n) {
                 RayRegs ray;
-                loadRay(tileBlock(fb.pool[stop & 1] + (size_t)regionOf((uint32_t)s) * fb.regionCap * kRayPlanes, (i / kBlock) * kBlock), i % kBlock, ray);
+                loadRay(tileBlock(fb.pool[stop & 1] + (size_t)s * fb.regionCap * kRayPlanes, (i / kBlock) * kBlock), i % kBlock, ray);
                 if (pixOf(ray.pix) < fb.numPixels && laneOf(ray.pix) < fb.samples) finishPath(fb, ray, fb.quantTable);
             }
         }
